@@ -1,0 +1,391 @@
+// extern "C" surface of libdmmfods_hip.so (see include/dmmfods_hip.h) and the launch-list executor.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "plan.h"
+
+using namespace dmm;
+
+void plan_build_tables(dmm_plan* p);
+void plan_bind(dmm_plan* p, void* ws);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) return fail(DMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+extern "C" {
+
+const char* dmm_last_error(void) { return g_err.c_str(); }
+int dmm_version(void) { return 100; }
+
+int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
+  if (!desc || !out) return fail(DMM_ERR_INVALID, "null argument");
+  if (desc->num_blocks < 2 || desc->num_blocks > 8) return fail(DMM_ERR_INVALID, "num_blocks must be in [2, 8]");
+  if (desc->dtype != DMM_F32 && desc->dtype != DMM_F16) return fail(DMM_ERR_INVALID, "dtype must be DMM_F32 or DMM_F16");
+  if (desc->batch < 1) return fail(DMM_ERR_INVALID, "batch must be >= 1");
+  if (!(desc->loss_scale > 0)) return fail(DMM_ERR_INVALID, "loss_scale must be > 0");
+  dmm_plan* p = new dmm_plan();
+  p->desc = *desc;
+  try {
+    plan_build_tables(p);
+  } catch (const std::domain_error& e) {
+    delete p;
+    return fail(DMM_ERR_SHAPE, e.what());
+  } catch (const std::exception& e) {
+    delete p;
+    return fail(DMM_ERR_INVALID, e.what());
+  }
+  *out = p;
+  return DMM_OK;
+}
+
+void dmm_plan_destroy(dmm_plan* plan) { delete plan; }
+
+int dmm_plan_num_tensors(const dmm_plan* plan) { return plan ? (int)plan->tensors.size() : 0; }
+
+int dmm_plan_tensor_info(const dmm_plan* plan, int index, const char** name, int32_t* kind, int32_t* ndim, int64_t shape[4],
+                         int64_t* arena_offset) {
+  if (!plan || index < 0 || index >= (int)plan->tensors.size()) return fail(DMM_ERR_INVALID, "tensor index out of range");
+  const TensorInfo& t = plan->tensors[index];
+  if (name) *name = t.name.c_str();
+  if (kind) *kind = t.kind;
+  if (ndim) *ndim = t.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  if (arena_offset) *arena_offset = t.off;
+  return DMM_OK;
+}
+
+int64_t dmm_plan_num_params(const dmm_plan* plan) { return plan ? plan->nparams : 0; }
+int64_t dmm_plan_num_buffer_elems(const dmm_plan* plan) { return plan ? plan->nbuf : 0; }
+size_t dmm_plan_workspace_bytes(const dmm_plan* plan) { return plan ? plan->zero_bytes + plan->main_bytes : 0; }
+double dmm_plan_forward_flops(const dmm_plan* plan) { return plan ? plan->fwd_flops : 0; }
+
+int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float* params, float* grads, float* buffers) {
+  if (!plan || !workspace || !params || !grads || !buffers) return fail(DMM_ERR_INVALID, "null argument");
+  if (workspace_bytes < plan->zero_bytes + plan->main_bytes) return fail(DMM_ERR_INVALID, "workspace too small");
+  if ((uintptr_t)workspace % 256) return fail(DMM_ERR_INVALID, "workspace must be 256-byte aligned");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMM_ERR_NO_DEVICE, "no HIP device");
+  plan->params = params;
+  plan->grads = grads;
+  plan->buffers = buffers;
+  try {
+    plan_bind(plan, workspace);
+  } catch (const std::exception& e) {
+    return fail(DMM_ERR_INVALID, e.what());
+  }
+  HIPCHK(hipDeviceSynchronize());
+  plan->bound = true;
+  return DMM_OK;
+}
+
+static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st) {
+  const int dt = p->desc.dtype;
+  const bool mfma = p->desc.use_mfma != 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    Op& o = ops[i];
+    hipError_t e = hipSuccess;
+    switch (o.kind) {
+      case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, st); break;
+      case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, st); break;
+      case OP_CONVERT: e = launch_convert_input(o.cv, dt, st); break;
+      case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, st); break;
+      case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, st); break;
+      case OP_BNFIN: e = launch_bn_finalize(o.bf, st); break;
+      case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, st); break;
+      case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, st); break;
+      case OP_POOLBWD: e = launch_maxpool_bwd(o.mpb, dt, st); break;
+      case OP_BCE: e = launch_bce_metrics(o.bce, dt, st); break;
+      case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, st); break;
+      case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, st); break;
+      default: return fail(DMM_ERR_STATE, "unknown op");
+    }
+    if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
+  }
+  return DMM_OK;
+}
+
+int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_2, float* logits_out, int training, void* stream) {
+  if (!plan || !plan->bound) return fail(DMM_ERR_STATE, "plan not bound");
+  if (!stream_1 || !logits_out) return fail(DMM_ERR_INVALID, "null argument");
+  if (plan->desc.stream_2_in_channels > 0 && !stream_2) return fail(DMM_ERR_INVALID, "stream_2 required");
+  std::vector<Op>& ops = training ? plan->fwd_train : plan->fwd_eval;
+  for (int idx : (training ? plan->convert_ops_train : plan->convert_ops_eval)) {
+    Op& o = ops[idx];
+    if (o.epi == 0) { o.cv.src1 = stream_1; o.cv.src2 = nullptr; }
+    else if (o.epi == 1) { o.cv.src1 = stream_1; o.cv.src2 = stream_2; }
+    else { o.cv.src1 = stream_2; o.cv.src2 = nullptr; }
+  }
+  ops[training ? plan->logits_op_train : plan->logits_op_eval].c.logits = logits_out;
+  return run_ops(plan, ops, (hipStream_t)stream);
+}
+
+int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream) {
+  if (!plan || !plan->bound) return fail(DMM_ERR_STATE, "plan not bound");
+  if (!logits || !target) return fail(DMM_ERR_INVALID, "null argument");
+  Op& b = plan->bwd[plan->bce_op];
+  b.bce.logits = logits;
+  b.bce.target = target;
+  int rc = run_ops(plan, plan->bwd, (hipStream_t)stream);
+  if (rc) return rc;
+  if (metrics_out) HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DMM_OK;
+}
+
+int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream) {
+  if (!plan || !plan->bound) return fail(DMM_ERR_STATE, "plan not bound");
+  if (!dlogits) return fail(DMM_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const BceArgs& b = plan->bwd[plan->bce_op].bce;
+  ConvertArgs cv;
+  memset(&cv, 0, sizeof(cv));
+  cv.src1 = dlogits; cv.C1 = b.NC; cv.dst = b.dlogits; cv.B = b.B; cv.H = b.H; cv.W = b.W;
+  cv.scale = plan->desc.loss_scale;
+  HIPCHK(launch_convert_input(cv, plan->desc.dtype, st));
+  std::vector<Op> rest(plan->bwd.begin() + plan->bce_op + 1, plan->bwd.end());
+  return run_ops(plan, rest, st);
+}
+
+int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream) {
+  if (!plan || !plan->bound) return fail(DMM_ERR_STATE, "plan not bound");
+  if (!logits || !target || !metrics_out) return fail(DMM_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(plan->metrics, 0, plan->metrics_bytes, st));
+  Op o = plan->bce_only;
+  o.bce.logits = logits;
+  o.bce.target = target;
+  HIPCHK(launch_bce_metrics(o.bce, plan->desc.dtype, st));
+  HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, st));
+  return DMM_OK;
+}
+
+int dmm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(DMM_ERR_INVALID, "bad Adam argument");
+  AdamArgs a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = (size_t)n;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  a.step_size = (float)(lr / bc1);
+  a.bc2_sqrt = (float)std::sqrt(bc2);
+  a.grad_scale = grad_scale;
+  HIPCHK(launch_adam(a, (hipStream_t)stream));
+  return DMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single-kernel entry points
+namespace {
+struct OneConv {
+  int esz, SLOT, BK;
+  int Ho, Wo, Hout, Wout, ostride, istride;
+  std::vector<std::vector<Tap>> phase_taps;
+  std::vector<std::pair<int, int>> phase_xy;
+  int Cst;  // storage channels of the input
+};
+int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+bool geometry(const dmm_conv_desc* d, OneConv& g) {
+  g.esz = (int)dtype_size(d->dtype);
+  g.SLOT = 16 / g.esz;
+  g.BK = 4 * g.SLOT;
+  g.Cst = d->Cin;
+  g.ostride = 1;
+  g.istride = 1;
+  if (d->Cin % 8 || d->Cout % 8 == 7) return false;
+  if (d->transposed) {
+    g.Ho = d->H; g.Wo = d->W; g.Hout = 2 * d->H; g.Wout = 2 * d->W; g.ostride = 2;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) { g.phase_taps.push_back(taps_convT_phase(py, px)); g.phase_xy.push_back({py, px}); }
+    return true;
+  }
+  if (d->mode == 2) { g.Ho = d->H / 2; g.Wo = d->W / 2; g.phase_taps.push_back(taps_conv(1, 1, 0)); }
+  else if (d->mode == 1) { g.Ho = 2 * d->H; g.Wo = 2 * d->W; g.phase_taps.push_back(taps_conv(d->R, d->S, d->pad)); }
+  else {
+    g.Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+    g.Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+    g.istride = d->stride;
+    g.phase_taps.push_back(taps_conv(d->R, d->S, d->pad));
+  }
+  g.Hout = g.Ho; g.Wout = g.Wo;
+  g.phase_xy.push_back({0, 0});
+  return true;
+}
+
+struct Scratch {
+  uint8_t* base;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    off = (off + 255) / 256 * 256;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+// builds forward pack descriptors (one per phase); returns bytes used
+size_t layout_fwd(const dmm_conv_desc* d, const OneConv& g, uint8_t* scratch, const float* w, float* dw, std::vector<PackDesc>& packs,
+                  PackDesc** dev_descs, int** dev_prefix, std::vector<int>& prefix, int& total_rows) {
+  Scratch S{scratch};
+  *dev_descs = (PackDesc*)S.take(8 * sizeof(PackDesc));
+  *dev_prefix = (int*)S.take(8 * sizeof(int));
+  total_rows = 0;
+  const long long RS = (long long)d->R * d->S;
+  for (size_t ph = 0; ph < g.phase_taps.size(); ++ph) {
+    PackDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.w = w; pd.gw = dw;
+    pd.N = d->Cout; pd.Npad = rup(d->Cout, 32); pd.nseg = 1;
+    if (!d->transposed) { pd.sn = d->Cin * RS; pd.sk = RS; } else { pd.sn = RS; pd.sk = (long long)d->Cout * RS; }
+    pd.st = 1;
+    fill_pack_seg(pd.seg[0], g.phase_taps[ph], d->Cin, g.Cst, 0, g.BK);
+    const size_t elems = (size_t)pd.seg[0].nchunks * pd.Npad * g.BK;
+    pd.dst = S.take(elems * g.esz);
+    pd.dpack = (float*)S.take(elems * sizeof(float));
+    prefix.push_back(total_rows);
+    total_rows += pd.seg[0].nchunks * pd.Npad;
+    packs.push_back(pd);
+  }
+  return S.off;
+}
+}  // namespace
+
+size_t dmm_conv_scratch_bytes(const dmm_conv_desc* d) {
+  OneConv g;
+  if (!d || !geometry(d, g)) return 0;
+  std::vector<PackDesc> packs;
+  std::vector<int> prefix;
+  PackDesc* dd; int* dp; int tr;
+  size_t fwd = layout_fwd(d, g, nullptr, nullptr, nullptr, packs, &dd, &dp, prefix, tr);
+  // dgrad pack: [chunks][rup(Cin,32)][BK] with K' = R*S*rup(Cout,8)
+  const size_t dg = (size_t)((d->R * d->S * rup(d->Cout, 8) + g.BK - 1) / g.BK + 16) * rup(d->Cin, 32) * g.BK * g.esz;
+  return fwd + dg + 4096;
+}
+
+static void fill_one_seg(Seg& s, const dmm_conv_desc* d, const OneConv& g, const void* x, const float* scale, const float* shift,
+                         const std::vector<Tap>& taps) {
+  memset(&s, 0, sizeof(s));
+  s.src = x; s.ld = g.Cst; s.Hs = d->H; s.Ws = d->W; s.C = g.Cst; s.Cpad = g.Cst;
+  s.mode = d->transposed ? 0 : d->mode;
+  s.istride = g.istride;
+  if (d->bn_relu) { s.scale = scale; s.shift = shift; }
+  fill_seg_taps(s, taps, g.BK);
+}
+
+int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, const float* scale, const float* shift, void* y,
+                     double* stats, void* scratch, void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g)) return fail(DMM_ERR_INVALID, "unsupported conv descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<PackDesc> packs;
+  std::vector<int> prefix;
+  PackDesc* dd; int* dp; int total_rows;
+  layout_fwd(d, g, (uint8_t*)scratch, w, nullptr, packs, &dd, &dp, prefix, total_rows);
+  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(launch_pack(dd, dp, (int)packs.size(), total_rows, d->dtype, st));
+  if (stats) HIPCHK(hipMemsetAsync(stats, 0, 2 * d->Cout * sizeof(double), st));
+  for (size_t ph = 0; ph < packs.size(); ++ph) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = 1;
+    fill_one_seg(a.seg[0], d, g, x, scale, shift, g.phase_taps[ph]);
+    a.B = d->B; a.Ho = g.Ho; a.Wo = g.Wo; a.M = d->B * g.Ho * g.Wo;
+    a.wpack = packs[ph].dst; a.N = d->Cout; a.Npad = packs[ph].Npad;
+    a.out = y; a.ldo = d->Cout; a.Hout = g.Hout; a.Wout = g.Wout; a.ostride = g.ostride;
+    a.py = g.phase_xy[ph].first; a.px = g.phase_xy[ph].second;
+    if (stats) { a.stat_sum = stats; a.stat_sq = stats + d->Cout; }
+    HIPCHK(launch_igemm(a, d->dtype, EPI_STORE, d->use_mfma != 0, st));
+  }
+  return DMM_OK;
+}
+
+int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, float* dw, void* scratch,
+                   void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g)) return fail(DMM_ERR_INVALID, "unsupported conv descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<PackDesc> packs;
+  std::vector<int> prefix;
+  PackDesc* dd; int* dp; int total_rows;
+  const size_t used = layout_fwd(d, g, (uint8_t*)scratch, dw /*unused as w*/, dw, packs, &dd, &dp, prefix, total_rows);
+  HIPCHK(hipMemsetAsync(scratch, 0, used, st));
+  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (size_t ph = 0; ph < packs.size(); ++ph) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = 1;
+    fill_one_seg(a.seg[0], d, g, x, scale, shift, g.phase_taps[ph]);
+    a.B = d->B; a.Ho = g.Ho; a.Wo = g.Wo; a.M = d->B * g.Ho * g.Wo;
+    a.dy.src = dy; a.dy.ld = d->Cout;
+    a.N = d->Cout; a.Npad = packs[ph].Npad;
+    a.Hout = g.Hout; a.Wout = g.Wout; a.ostride = g.ostride; a.py = g.phase_xy[ph].first; a.px = g.phase_xy[ph].second;
+    a.dpack = (float*)packs[ph].dpack;
+    HIPCHK(launch_wgrad(a, d->dtype, d->use_mfma != 0, st));
+  }
+  const size_t wn = (size_t)d->Cin * d->Cout * d->R * d->S;
+  HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
+  HIPCHK(launch_unpack(dd, dp, (int)packs.size(), total_rows, d->dtype, 1.0f, st));
+  return DMM_OK;
+}
+
+int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift, void* gx,
+                   double* red, void* scratch, void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g) || !d->bn_relu) return fail(DMM_ERR_INVALID, "unsupported conv descriptor (dgrad needs bn_relu)");
+  if (d->mode == 0 && !d->transposed && d->stride != 1) return fail(DMM_ERR_INVALID, "strided conv dgrad is not on the hot path");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<Tap> taps;
+  int istride = 1, rH = d->H, rW = d->W, pool2 = 0, ostride = 1;
+  if (d->transposed) { taps = taps_convT_dgrad(); istride = 2; }
+  else if (d->mode == 2) { taps = taps_conv(1, 1, 0); rH = d->H / 2; rW = d->W / 2; pool2 = 1; ostride = 2; }
+  else if (d->mode == 1) { taps = taps_up2_merged_dgrad(); istride = 2; }
+  else taps = taps_conv_dgrad(d->R, d->S, d->pad);
+  Scratch S{(uint8_t*)scratch};
+  PackDesc* dd = (PackDesc*)S.take(sizeof(PackDesc));
+  int* dp = (int*)S.take(sizeof(int));
+  PackDesc pd;
+  memset(&pd, 0, sizeof(pd));
+  const long long RS = (long long)d->R * d->S;
+  pd.w = w;
+  pd.N = d->Cin; pd.Npad = rup(d->Cin, 32); pd.nseg = 1;
+  if (!d->transposed) { pd.sn = RS; pd.sk = d->Cin * RS; } else { pd.sn = (long long)d->Cout * RS; pd.sk = RS; }
+  pd.st = 1;
+  const int kc = rup(d->Cout, 8);
+  fill_pack_seg(pd.seg[0], taps, d->Cout, kc, 0, g.BK);
+  pd.dst = S.take((size_t)pd.seg[0].nchunks * pd.Npad * g.BK * g.esz);
+  int zero = 0;
+  HIPCHK(hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dp, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(launch_pack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, st));
+  HIPCHK(hipMemsetAsync(red, 0, 2 * d->Cin * sizeof(double), st));
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nseg = 1;
+  Seg& s = a.seg[0];
+  s.src = dy; s.ld = d->Cout; s.Hs = g.Hout; s.Ws = g.Wout; s.C = kc; s.Cpad = kc; s.mode = G_PLAIN; s.istride = istride;
+  fill_seg_taps(s, taps, g.BK);
+  a.B = d->B; a.Ho = rH; a.Wo = rW; a.M = d->B * rH * rW;
+  a.wpack = pd.dst; a.N = d->Cin; a.Npad = pd.Npad;
+  a.out = gx; a.ldo = d->Cin; a.Hout = d->H; a.Wout = d->W; a.ostride = ostride;
+  a.bx = x; a.ldbx = d->Cin; a.bscale = scale; a.bshift = shift;
+  a.red1 = red; a.red2 = red + d->Cin;
+  a.accumulate = 0; a.pool2 = pool2;
+  HIPCHK(launch_igemm(a, d->dtype, EPI_BNBWD, d->use_mfma != 0, st));
+  return DMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Shared definitions for the gfx950 (MI355X) kernels of the Dense_U_Net_lidar hot path.
+// Layout convention everywhere: activations are NHWC ("pixel-major"): element (b,y,x,c) of a tensor with
+// pixel stride ld lives at ((b*H + y)*W + x)*ld + c.  A "slot" is 16 bytes of channels (8 x f16 or 4 x f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dmm {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum DType { DT_F32 = 0, DT_F16 = 1 };
+static inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : 4; }
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int SLOT = 4;
+  typedef f32x4 vec;
+};
+template <> struct TT<f16> {
+  static constexpr int SLOT = 8;
+  typedef f16x8 vec;
+};
+
+constexpr int MAX_TAPS = 52;
+constexpr int BM = 128;        // rows (pixels) per workgroup tile
+constexpr int NTHREADS = 256;  // 4 waves of 64
+constexpr int ROWB = 80;       // LDS bytes per tile row: 64 B of K-chunk + 16 B pad (conflict-free ds_read_b128)
+
+enum GatherMode { G_PLAIN = 0, G_UP2 = 1, G_POOL2 = 2 };
+enum Epilogue { EPI_STORE = 0, EPI_BNBWD = 1, EPI_LOGITS = 2 };
+
+// One K-segment of the gathered ("A") operand of an implicit-GEMM convolution.
+struct Seg {
+  const void* src;     // T*, NHWC, pixel stride ld
+  const void* src2;    // companion tensor for the effective-gradient prologue (nullable)
+  const float* scale;  // BN+ReLU prologue: v = max(v*scale[c] + shift[c], 0)   (nullable)
+  const float* shift;
+  const float* q;      // effective gradient: v = src + q[c] + r[c]*src2         (nullable)
+  const float* r;
+  int ld, ld2;
+  int Hs, Ws;   // source spatial size
+  int C;        // real channels (multiple of SLOT)
+  int Cpad;     // channels per tap in the K enumeration (multiple of SLOT, >= C)
+  int ntaps;
+  int nchunks;  // ceil(ntaps*Cpad / BK)
+  int mode;     // GatherMode
+  int istride;  // source pixel = row pixel * istride + tap offset
+  short taps[MAX_TAPS];  // (dy & 0xff) | ((dx & 0xff) << 8)
+};
+
+struct ConvArgs {
+  Seg seg[2];
+  int nseg;
+  int B, Ho, Wo, M;  // row grid (b, y, x), M = B*Ho*Wo
+  const void* wpack; // T* packed weights [chunk][Npad][BK]
+  int N, Npad;
+  // output pixel of row (b,y,x) = (b, y*ostride + py, x*ostride + px) in a tensor Hout x Wout, pixel stride ldo
+  void* out;
+  int ldo, coff, Hout, Wout, ostride, py, px;
+  // EPI_STORE: per-channel sum / sum of squares of the stored values (nullable), indexed like out channels
+  double* stat_sum;
+  double* stat_sq;
+  // EPI_LOGITS: fp32 NCHW logits (B, N, Hout, Wout)
+  float* logits;
+  // EPI_BNBWD: acc = d(relu(bn(x))).  x and the gradient buffer `out` share the pixel mapping above.
+  const void* bx;
+  int ldbx;
+  const float* bscale;
+  const float* bshift;
+  double* red1;    // sum dz
+  double* red2;    // sum dz*x
+  int accumulate;  // out += s*dz  instead of  out = s*dz
+  int pool2;       // each row is a 2x2-average-pooled pixel: distribute 0.25*acc to the 4 source pixels
+};
+
+// Weight-gradient GEMM:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k], same A gather as the forward conv.
+struct WgradArgs {
+  Seg seg[2];
+  int nseg;
+  int B, Ho, Wo, M;
+  Seg dy;        // the dY operand: uses src/src2/q/r/ld/ld2 and C = N; pixel mapping below
+  int N, Npad;
+  int Hout, Wout, ostride, py, px, coff;
+  float* dpack;  // fp32 packed gradient [chunk][Npad][BK]
+  int rows_per_split;  // multiple of BM
+  int kgroups;         // number of K groups (each WG_CHUNKS chunks)
+};
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+#endif
+
+}  // namespace dmm

@@ -1,0 +1,130 @@
+// Device-side operand gather shared by the implicit-GEMM forward/dgrad kernel and the wgrad kernel.
+// A K-dimension "chunk" is 64 bytes (BK = 4 slots) of the enumeration  k = tap*Cpad + c  over a segment.
+#pragma once
+#include "common.h"
+
+namespace dmm {
+
+template <typename T>
+__device__ __forceinline__ void vec_to_f32(const typename TT<T>::vec& v, float (&f)[TT<T>::SLOT]) {
+#pragma unroll
+  for (int i = 0; i < TT<T>::SLOT; ++i) f[i] = to_f32(v[i]);
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec f32_to_vec(const float (&f)[TT<T>::SLOT]) {
+  typename TT<T>::vec v;
+#pragma unroll
+  for (int i = 0; i < TT<T>::SLOT; ++i) v[i] = from_f32<T>(f[i]);
+  return v;
+}
+template <int S>
+__device__ __forceinline__ void load_f32s(const float* p, float (&f)[S]) {
+#pragma unroll
+  for (int i = 0; i < S; i += 4) {
+    f32x4 t = *(const f32x4*)(p + i);
+    f[i] = t[0]; f[i + 1] = t[1]; f[i + 2] = t[2]; f[i + 3] = t[3];
+  }
+}
+
+// Position of a thread in the K enumeration: segment, tap, channel; `left` = chunks left in this segment.
+struct KWalk {
+  int s, tap, c, left;
+};
+
+template <int SLOT>
+__device__ __forceinline__ void kw_enter(KWalk& w, const Seg* seg, int s, int j) {
+  w.s = s;
+  w.left = seg[s].nchunks;
+  w.tap = 0;
+  w.c = j * SLOT;
+  const int cp = seg[s].Cpad;
+  while (w.c >= cp) { w.c -= cp; ++w.tap; }
+}
+template <int SLOT>
+__device__ __forceinline__ void kw_next(KWalk& w, const Seg* seg, int nseg, int j) {
+  if (--w.left == 0) {
+    if (w.s + 1 < nseg) kw_enter<SLOT>(w, seg, w.s + 1, j);
+    else w.tap = 1 << 20;  // past the end: gathers return zero
+  } else {
+    w.c += 4 * SLOT;
+    const int cp = seg[w.s].Cpad;
+    while (w.c >= cp) { w.c -= cp; ++w.tap; }
+  }
+}
+
+// One 16-byte slot of the gathered operand for row pixel (b,y,x) at K position (tap, c) of segment sg,
+// with the segment's prologue applied.  Out-of-image taps, channels >= C, taps >= ntaps and invalid rows
+// give zeros (zero padding applies AFTER BN+ReLU, as in conv(relu(bn(x)))).
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b, int y, int x, bool rowvalid,
+                                                           int tap, int c) {
+  constexpr int S = TT<T>::SLOT;
+  typedef typename TT<T>::vec V;
+  V zero;
+#pragma unroll
+  for (int i = 0; i < S; ++i) zero[i] = (T)0;
+  if (!rowvalid || tap >= sg.ntaps || c >= sg.C) return zero;
+  const T* base = (const T*)sg.src;
+  if (sg.mode == G_POOL2) {
+    float acc[S], sc[S], sh[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) acc[i] = 0.f;
+    const bool bn = sg.scale != nullptr;
+    if (bn) { load_f32s<S>(sg.scale + c, sc); load_f32s<S>(sg.shift + c, sh); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const size_t pix = ((size_t)(b * sg.Hs + 2 * y + (a >> 1)) * sg.Ws + (2 * x + (a & 1)));
+      V v = *(const V*)(base + pix * sg.ld + c);
+      float f[S];
+      vec_to_f32<T>(v, f);
+#pragma unroll
+      for (int i = 0; i < S; ++i) acc[i] += bn ? fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f) : f[i];
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) acc[i] *= 0.25f;
+    return f32_to_vec<T>(acc);
+  }
+  const int t = sg.taps[tap];
+  const int dy = (int)(signed char)(t & 0xff), dx = (int)(signed char)((t >> 8) & 0xff);
+  int sy = y * sg.istride + dy, sx = x * sg.istride + dx;
+  if (sg.mode == G_UP2) {
+    if (sy < 0 || sx < 0 || sy >= 2 * sg.Hs || sx >= 2 * sg.Ws) return zero;
+    sy >>= 1;
+    sx >>= 1;
+  } else {
+    if (sy < 0 || sx < 0 || sy >= sg.Hs || sx >= sg.Ws) return zero;
+  }
+  const size_t pix = ((size_t)(b * sg.Hs + sy) * sg.Ws + sx);
+  V v = *(const V*)(base + pix * sg.ld + c);
+  if (sg.scale != nullptr) {
+    float f[S], sc[S], sh[S];
+    vec_to_f32<T>(v, f);
+    load_f32s<S>(sg.scale + c, sc);
+    load_f32s<S>(sg.shift + c, sh);
+#pragma unroll
+    for (int i = 0; i < S; ++i) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
+    return f32_to_vec<T>(f);
+  }
+  if (sg.q != nullptr) {
+    V v2 = *(const V*)((const T*)sg.src2 + pix * sg.ld2 + c);
+    float f[S], f2[S], q[S], r[S];
+    vec_to_f32<T>(v, f);
+    vec_to_f32<T>(v2, f2);
+    load_f32s<S>(sg.q + c, q);
+    load_f32s<S>(sg.r + c, r);
+#pragma unroll
+    for (int i = 0; i < S; ++i) f[i] = f[i] + fmaf(r[i], f2[i], q[i]);
+    return f32_to_vec<T>(f);
+  }
+  return v;
+}
+
+// Decompose a row index into (b, y, x) of the row grid.
+__device__ __forceinline__ void row_to_byx(int m, int Ho, int Wo, int& b, int& y, int& x) {
+  x = m % Wo;
+  const int t = m / Wo;
+  y = t % Ho;
+  b = t / Ho;
+}
+
+}  // namespace dmm

@@ -1,0 +1,321 @@
+// Implicit-GEMM convolution for gfx950: out[m][n] = sum_k A[m][k] * W[n][k]
+//   m = output pixel (NHWC rows), k = (tap, input channel), n = output channel.
+// One kernel serves forward convolutions (1x1, 3x3, 5x5, 7x7 s2, transposed 3x3 s2 as 4 gather phases,
+// 2x2-avg-pool-then-1x1 transitions, nearest-upsampled sources) and data gradients (the same gather applied
+// to the output gradient with re-packed weights), selected by the tap table / gather mode in ConvArgs and by
+// the epilogue:
+//   EPI_STORE  : write the tile (T) and accumulate per-channel sum / sum-of-squares (BatchNorm batch stats)
+//   EPI_BNBWD  : acc is d(relu(bn(x))): apply the ReLU mask, reduce sum(dz), sum(dz*x) per channel and
+//                scatter s*dz into the gradient buffer of x (assign or accumulate)
+//   EPI_LOGITS : write fp32 NCHW logits
+// Tile: 128 rows x BN columns per 256-thread workgroup; each wave owns 32 rows x BN columns as BN/32
+// v_mfma_f32_32x32x16_f16 (or 32x32x2_f32) accumulators.  K advances in 64-byte chunks, register-staged
+// through a double-buffered LDS image with 80-byte rows (conflict-free ds_read_b128).
+#include "common.h"
+#include "gather.h"
+
+namespace dmm {
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+  static __device__ __forceinline__ void run(f32x16& acc, const f16x8& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // lane (r, h) holds k = 8s + 4h + i of row r: the i-th 32x32x2 MFMA pairs k(h=0,i) with k(h=1,i)
+  static __device__ __forceinline__ void run(f32x16& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN>
+struct IgemmSmem {
+  static constexpr int SLOT = TT<T>::SLOT;
+  static constexpr int A_BYTES = BM * ROWB;
+  static constexpr int B_BYTES = BN * ROWB;
+  static constexpr int STAGE_PITCH_T = BN + SLOT;  // elements of T
+  static constexpr int STAGE_PITCH_F = BN + 4;     // floats
+  static constexpr int MAIN = 2 * (A_BYTES + B_BYTES);
+  static constexpr int STAGE_T = BM * STAGE_PITCH_T * (int)sizeof(T);
+  static constexpr int STAGE_F = BM * STAGE_PITCH_F * 4;
+  static constexpr int EXTRA = BM * 4 + 2 * BN * 4;  // rowpix + reduction scratch
+  static constexpr int bytes(int epi) {
+    int st = (epi == EPI_STORE) ? STAGE_T : STAGE_F;
+    int m = MAIN > st ? MAIN : st;
+    return m + EXTRA;
+  }
+};
+
+template <typename T, int BN, int EPI, bool MFMA>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
+  constexpr int SLOT = TT<T>::SLOT;
+  constexpr int BK = 4 * SLOT;
+  typedef typename TT<T>::vec V;
+  typedef IgemmSmem<T, BN> SM;
+  constexpr int NT = BN / 32;
+  constexpr int BSLOTS = (BN * 4 + NTHREADS - 1) / NTHREADS;  // B slots per thread per chunk
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAINB = (SM::MAIN > (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F)) ? SM::MAIN
+                        : (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F);
+  int* rowpix = (int*)(smem + MAINB);
+  float* red = (float*)(smem + MAINB + BM * 4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ntiles = a.Npad / BN;
+  const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+
+  // ---- per-thread A rows (two rows, one slot column) ----
+  const int j = tid & 3;
+  const int ar0 = tid >> 2;
+  int rb[2], ry[2], rx[2];
+  bool rv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + ar0 + 64 * i;
+    rv[i] = m < a.M;
+    row_to_byx(rv[i] ? m : 0, a.Ho, a.Wo, rb[i], ry[i], rx[i]);
+  }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int pb, py_, px_;
+    row_to_byx(m < a.M ? m : 0, a.Ho, a.Wo, pb, py_, px_);
+    rowpix[tid] = m < a.M ? (pb * a.Hout + py_ * a.ostride + a.py) * a.Wout + px_ * a.ostride + a.px : -1;
+  }
+  if (tid < 2 * BN) red[tid] = 0.f;
+
+  int total = 0;
+  for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  KWalk kw;
+  kw_enter<SLOT>(kw, a.seg, 0, j);
+  const T* wp = (const T*)a.wpack;
+
+  V areg[2], breg[BSLOTS];
+  auto load_chunk = [&](int gchunk) {
+    const Seg& sg = a.seg[kw.s];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) areg[i] = gather_slot<T>(sg, rb[i], ry[i], rx[i], rv[i], kw.tap, kw.c);
+#pragma unroll
+    for (int i = 0; i < BSLOTS; ++i) {
+      const int q = tid + i * NTHREADS;
+      if (q < BN * 4) {
+        const int n = q >> 2, jj = q & 3;
+        breg[i] = *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
+    unsigned char* Bs = As + SM::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(V*)(As + (ar0 + 64 * i) * ROWB + j * 16) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BSLOTS; ++i) {
+      const int q = tid + i * NTHREADS;
+      if (q < BN * 4) *(V*)(Bs + (q >> 2) * ROWB + (q & 3) * 16) = breg[i];
+    }
+  };
+
+  const int r = lane & 31, h = lane >> 5;
+  load_chunk(0);
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    store_chunk(buf);
+    __syncthreads();
+    if (it + 1 < total) {
+      kw_next<SLOT>(kw, a.seg, a.nseg, j);
+      load_chunk(it + 1);
+    }
+    const unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
+    const unsigned char* Bs = As + SM::A_BYTES;
+    if (MFMA) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const V av = *(const V*)(As + (32 * wave + r) * ROWB + s * 32 + h * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const V bv = *(const V*)(Bs + (32 * t + r) * ROWB + s * 32 + h * 16);
+          Mma<T>::run(acc[t], av, bv);
+        }
+      }
+    } else {
+      // scalar check path with the same accumulator layout as the MFMA (debug / bring-up)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const T* ap = (const T*)(As + row * ROWB);
+          const T* bp = (const T*)(Bs + (32 * t + r) * ROWB);
+          float s = 0.f;
+          for (int k = 0; k < BK; ++k) s = fmaf(to_f32(ap[k]), to_f32(bp[k]), s);
+          acc[t][i] += s;
+        }
+    }
+  }
+  __syncthreads();  // all waves done with the operand image; reuse it for epilogue staging
+
+  // ---- stage the accumulators through LDS: Cs[row][col] ----
+  if (EPI == EPI_STORE) {
+    T* Cs = (T*)smem;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+        Cs[row * SM::STAGE_PITCH_T + 32 * t + r] = from_f32<T>(acc[t][i]);
+      }
+  } else {
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+        Cs[row * SM::STAGE_PITCH_F + 32 * t + r] = acc[t][i];
+      }
+  }
+  __syncthreads();
+
+  if (EPI == EPI_LOGITS) {
+    const float* Cs = (const float*)smem;
+    const size_t plane = (size_t)a.Hout * a.Wout;
+    for (int idx = tid; idx < BM * a.N; idx += NTHREADS) {
+      const int n = idx / BM, row = idx - n * BM;
+      const int pix = rowpix[row];
+      if (pix < 0 || n0 + n >= a.N) continue;
+      const int bimg = pix / (int)plane;
+      const int rem = pix - bimg * (int)plane;
+      a.logits[((size_t)bimg * a.N + n0 + n) * plane + rem] = Cs[row * SM::STAGE_PITCH_F + n];
+    }
+    return;
+  }
+
+  constexpr int NCV = BN / SLOT;       // slot columns in the tile
+  constexpr int RPP = NTHREADS / NCV;  // rows per pass
+  const int cv = tid % NCV, rr = tid / NCV;
+  const int n = n0 + cv * SLOT;
+  const bool colvalid = n < a.N;
+  float s1[SLOT], s2[SLOT];
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+
+  if (EPI == EPI_STORE) {
+    const T* Cs = (const T*)smem;
+    T* out = (T*)a.out;
+    for (int row = rr; row < BM; row += RPP) {
+      const int pix = rowpix[row];
+      if (pix < 0 || !colvalid) continue;
+      const V v = *(const V*)(Cs + row * SM::STAGE_PITCH_T + cv * SLOT);
+      *(V*)(out + (size_t)pix * a.ldo + n) = v;
+      float f[SLOT];
+      vec_to_f32<T>(v, f);
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
+    }
+    if (a.stat_sum == nullptr) return;
+  } else {  // EPI_BNBWD
+    const float* Cs = (const float*)smem;
+    const T* bx = (const T*)a.bx;
+    T* g = (T*)a.out;
+    float sc[SLOT], sh[SLOT];
+    if (colvalid) { load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh); }
+    const int nsub = a.pool2 ? 4 : 1;
+    const float wgt = a.pool2 ? 0.25f : 1.f;
+    for (int row = rr; row < BM; row += RPP) {
+      const int pix = rowpix[row];
+      if (pix < 0 || !colvalid) continue;
+      float av[SLOT];
+#pragma unroll
+      for (int i = 0; i < SLOT; i += 4) {
+        const f32x4 t4 = *(const f32x4*)(Cs + row * SM::STAGE_PITCH_F + cv * SLOT + i);
+        av[i] = t4[0]; av[i + 1] = t4[1]; av[i + 2] = t4[2]; av[i + 3] = t4[3];
+      }
+      for (int sub = 0; sub < nsub; ++sub) {
+        const size_t p = (size_t)pix + (sub >> 1) * a.Wout + (sub & 1);
+        float xf[SLOT], gf[SLOT];
+        vec_to_f32<T>(*(const V*)(bx + p * a.ldbx + n), xf);
+        if (a.accumulate) vec_to_f32<T>(*(const V*)(g + p * a.ldo + n), gf);
+#pragma unroll
+        for (int i = 0; i < SLOT; ++i) {
+          const float dz = (fmaf(xf[i], sc[i], sh[i]) > 0.f) ? av[i] * wgt : 0.f;
+          s1[i] += dz;
+          s2[i] = fmaf(dz, xf[i], s2[i]);
+          gf[i] = (a.accumulate ? gf[i] : 0.f) + sc[i] * dz;
+        }
+        *(V*)(g + p * a.ldo + n) = f32_to_vec<T>(gf);
+      }
+    }
+  }
+
+  // ---- per-channel reductions: threads -> LDS -> one fp64 atomic per channel per workgroup ----
+  if (colvalid) {
+#pragma unroll
+    for (int i = 0; i < SLOT; ++i) {
+      atomicAdd(&red[cv * SLOT + i], s1[i]);
+      atomicAdd(&red[BN + cv * SLOT + i], s2[i]);
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < a.N) {
+    double* d1 = (EPI == EPI_STORE) ? a.stat_sum : a.red1;
+    double* d2 = (EPI == EPI_STORE) ? a.stat_sq : a.red2;
+    atomic_add_f64(d1 + n0 + tid, (double)red[tid]);
+    atomic_add_f64(d2 + n0 + tid, (double)red[BN + tid]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BN, int EPI>
+static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
+  const int mtiles = (a.M + BM - 1) / BM;
+  const int ntiles = a.Npad / BN;
+  dim3 grid(mtiles * ntiles), block(NTHREADS);
+  const int smem = IgemmSmem<T, BN>::bytes(EPI);
+  auto kern = mfma ? igemm_kernel<T, BN, EPI, true> : igemm_kernel<T, BN, EPI, false>;
+  static bool attr_done[2] = {false, false};
+  if (smem > 48 * 1024 && !attr_done[mfma]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_done[mfma] = true;
+  }
+  hipLaunchKernelGGL(kern, grid, block, smem, st, a);
+  return hipGetLastError();
+}
+
+template <typename T, int EPI>
+static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
+  if (EPI == EPI_BNBWD) {  // float staging: keep the tile at 64 columns
+    if (a.Npad % 64 == 0) return launch_bn<T, 64, EPI>(a, mfma, st);
+    return launch_bn<T, 32, EPI>(a, mfma, st);
+  }
+  if (EPI == EPI_LOGITS) return launch_bn<T, 32, EPI>(a, mfma, st);
+  if (a.Npad % 128 == 0) return launch_bn<T, 128, EPI>(a, mfma, st);
+  if (a.Npad % 64 == 0) return launch_bn<T, 64, EPI>(a, mfma, st);
+  return launch_bn<T, 32, EPI>(a, mfma, st);
+}
+
+hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st) {
+  if (a.M <= 0) return hipSuccess;
+  if (dtype == DT_F16) {
+    if (epi == EPI_STORE) return launch_epi<f16, EPI_STORE>(a, mfma, st);
+    if (epi == EPI_BNBWD) return launch_epi<f16, EPI_BNBWD>(a, mfma, st);
+    return launch_epi<f16, EPI_LOGITS>(a, mfma, st);
+  }
+  if (epi == EPI_STORE) return launch_epi<float, EPI_STORE>(a, mfma, st);
+  if (epi == EPI_BNBWD) return launch_epi<float, EPI_BNBWD>(a, mfma, st);
+  return launch_epi<float, EPI_LOGITS>(a, mfma, st);
+}
+
+}  // namespace dmm

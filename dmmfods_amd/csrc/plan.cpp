@@ -1,0 +1,889 @@
+// Plan builder for the Dense_U_Net_lidar training step on MI355X.
+//
+// Follows the reference topology  dmmfods/graphs/models/Dense_U_Net_lidar.py:29-267  (encoder = DenseNet without
+// norm5/classifier, optional second stream, mid-fusion concat module, U-Net decoder, heat-map head) but lays it out
+// for NHWC implicit-GEMM kernels:
+//   * every dense block lives in ONE preallocated buffer; a layer's 3x3 conv writes its growth channels in place, so
+//     torch.cat inside blocks disappears; blocks that feed a decoder skip carry the decoder's ConvTranspose output in
+//     a front region of the same buffer, so the decoder concat disappears too;
+//   * BatchNorm batch statistics are reduced in the producing kernel's epilogue (fp64 accumulators), BN+ReLU is
+//     applied in the consuming kernel's operand gather; nothing normalised is ever materialised;
+//   * transitions pool BEFORE their 1x1 conv (both are linear; 4x fewer FLOPs), nearest upsampling is index math;
+//   * BatchNorm backward is deferred: the dgrad epilogue stores s*dz and reduces sum(dz), sum(dz*x); the remaining
+//     per-channel affine term (q + r*x) is applied by whoever reads that gradient next.
+#include "plan.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+namespace dmm {
+
+// ------------------------------------------------------------------------------------------------ taps
+static unsigned tw1(int mt) { return 0xffffff00u | (unsigned)mt; }
+
+std::vector<Tap> taps_conv(int R, int S, int pad) {
+  std::vector<Tap> t;
+  for (int ky = 0; ky < R; ++ky)
+    for (int kx = 0; kx < S; ++kx) t.push_back({ky - pad, kx - pad, tw1(ky * S + kx)});
+  return t;
+}
+std::vector<Tap> taps_conv_dgrad(int R, int S, int pad) {
+  std::vector<Tap> t;
+  for (int ky = 0; ky < R; ++ky)
+    for (int kx = 0; kx < S; ++kx) t.push_back({pad - ky, pad - kx, tw1(ky * S + kx)});
+  return t;
+}
+// out[2i - 1 + k] += in[i] * w[k]:  even outputs use k = 1 (i = o/2), odd outputs k = 0 (i = (o+1)/2) and k = 2 (i = (o-1)/2)
+std::vector<Tap> taps_convT_phase(int py, int px) {
+  std::vector<std::pair<int, int>> ys, xs;  // (k, d)
+  if (py == 0) ys = {{1, 0}}; else ys = {{0, 1}, {2, 0}};
+  if (px == 0) xs = {{1, 0}}; else xs = {{0, 1}, {2, 0}};
+  std::vector<Tap> t;
+  for (auto& y : ys)
+    for (auto& x : xs) t.push_back({y.second, x.second, tw1(y.first * 3 + x.first)});
+  return t;
+}
+std::vector<Tap> taps_convT_dgrad() {
+  std::vector<Tap> t;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) t.push_back({ky - 1, kx - 1, tw1(ky * 3 + kx)});
+  return t;
+}
+// d a[z] = sum_{e in {0,1}} sum_ky dy[2z + e - ky + 1] w[ky]; offset o = e - ky + 1 in {-1,0,1,2} collects
+// ky sets {2}, {1,2}, {0,1}, {0}.
+std::vector<Tap> taps_up2_merged_dgrad() {
+  static const int sets[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};
+  std::vector<Tap> t;
+  for (int oy = 0; oy < 4; ++oy)
+    for (int ox = 0; ox < 4; ++ox) {
+      unsigned w = 0;
+      int cnt = 0;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+          const int ky = sets[oy][a], kx = sets[ox][b];
+          if (ky < 0 || kx < 0) continue;
+          w |= (unsigned)(ky * 3 + kx) << (8 * cnt++);
+        }
+      for (; cnt < 4; ++cnt) w |= 0xffu << (8 * cnt);
+      t.push_back({oy - 1, ox - 1, w});
+    }
+  return t;
+}
+
+void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK) {
+  if ((int)taps.size() > MAX_TAPS) throw std::runtime_error("too many taps");
+  s.ntaps = (int)taps.size();
+  for (int i = 0; i < s.ntaps; ++i) s.taps[i] = (short)((taps[i].dy & 0xff) | ((taps[i].dx & 0xff) << 8));
+  s.nchunks = (s.ntaps * s.Cpad + BK - 1) / BK;
+}
+void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK) {
+  p.Creal = Creal;
+  p.Cpad = Cpad;
+  p.koff = koff;
+  p.ntaps = (int)taps.size();
+  p.nchunks = (p.ntaps * Cpad + BK - 1) / BK;
+  for (int i = 0; i < p.ntaps; ++i) p.tapw[i] = taps[i].tapw;
+}
+
+// ------------------------------------------------------------------------------------------------ state_dict table
+namespace {
+
+struct TableBuilder {
+  std::vector<TensorInfo>& out;
+  int64_t np = 0, nb = 0;
+  void add(const std::string& name, int kind, std::initializer_list<int64_t> shape) {
+    TensorInfo t;
+    t.name = name;
+    t.kind = kind;
+    t.ndim = (int)shape.size();
+    int64_t n = 1;
+    int i = 0;
+    for (int k = 0; k < 4; ++k) t.shape[k] = 0;
+    for (auto s : shape) { t.shape[i++] = s; n *= s; }
+    if (kind <= DMM_T_BN_BIAS) { t.off = np; np += n; }
+    else if (kind <= DMM_T_BN_VAR) { t.off = nb; nb += n; }
+    else t.off = -1;
+    out.push_back(t);
+  }
+  void bn(const std::string& p, int64_t c) {
+    add(p + ".weight", DMM_T_BN_WEIGHT, {c});
+    add(p + ".bias", DMM_T_BN_BIAS, {c});
+    add(p + ".running_mean", DMM_T_BN_MEAN, {c});
+    add(p + ".running_var", DMM_T_BN_VAR, {c});
+    add(p + ".num_batches_tracked", DMM_T_BN_TRACKED, {});
+  }
+};
+
+struct Geo {  // channel algebra
+  int nb, k, bs, nif, s1, s2, nc, cbb;
+  int fusion;  // 0 no, 1 early, 2 mid
+  int net_in;
+  std::vector<int> L, cin, cout, nin, nf;
+  explicit Geo(const dmm_model_desc& d) {
+    nb = d.num_blocks; k = d.growth_rate; bs = d.bn_size; nif = d.num_init_features;
+    s1 = d.stream_1_in_channels; s2 = d.stream_2_in_channels; nc = d.num_classes; cbb = d.concat_before_block_num;
+    if (cbb == 1 && s2 == 0) fusion = 0;
+    else if (cbb == 1 && s2 > 0) fusion = 1;
+    else if (cbb > 1 && cbb <= nb) fusion = 2;
+    else throw std::invalid_argument("invalid fusion configuration (AttributeError in the reference, M:65)");
+    net_in = s1 + (fusion == 1 ? s2 : 0);
+    int c = nif;
+    for (int i = 0; i < nb; ++i) {
+      L.push_back(d.block_config[i]);
+      cin.push_back(c);
+      c += L[i] * k;
+      cout.push_back(c);
+      if (i != nb - 1) c /= 2;
+    }
+    std::vector<int> stack;
+    stack.push_back(nif + 2 * k);
+    for (int i = 0; i < nb; ++i) stack.push_back(cout[i]);
+    int num_in = stack.back(); stack.pop_back();
+    for (int i = 0; i < nb; ++i) {
+      const int f = stack.back(); stack.pop_back();
+      nin.push_back(num_in);
+      nf.push_back(f);
+      num_in = 2 * f;
+    }
+  }
+};
+
+void encoder_table(TableBuilder& tb, const std::string& p, const Geo& g, int in_ch, int upto) {
+  tb.add(p + ".conv0.weight", DMM_T_CONV, {g.nif, in_ch, 7, 7});
+  tb.bn(p + ".norm0", g.nif);
+  for (int b = 0; b < g.nb && b < upto; ++b) {
+    for (int l = 0; l < g.L[b]; ++l) {
+      const std::string q = p + ".denseblock" + std::to_string(b + 1) + ".denselayer" + std::to_string(l + 1);
+      const int c = g.cin[b] + l * g.k;
+      tb.bn(q + ".norm1", c);
+      tb.add(q + ".conv1.weight", DMM_T_CONV, {g.bs * g.k, c, 1, 1});
+      tb.bn(q + ".norm2", g.bs * g.k);
+      tb.add(q + ".conv2.weight", DMM_T_CONV, {g.k, g.bs * g.k, 3, 3});
+    }
+    if (b != g.nb - 1) {
+      const std::string q = p + ".transition" + std::to_string(b + 1);
+      tb.bn(q + ".norm", g.cout[b]);
+      tb.add(q + ".conv.weight", DMM_T_CONV, {g.cout[b] / 2, g.cout[b], 1, 1});
+    }
+  }
+}
+
+}  // namespace
+
+static void build_tensor_table(const dmm_model_desc& d, std::vector<TensorInfo>& out, int64_t& np, int64_t& nbuf) {
+  Geo g(d);
+  TableBuilder tb{out};
+  encoder_table(tb, "features", g, g.net_in, g.nb);
+  for (int j = 0; j < g.nb; ++j) {
+    const std::string p = "decoder.Transposed_Convolution_Sequence_" + std::to_string(j + 1);
+    tb.bn(p + ".norm0", g.nin[j]);
+    tb.add(p + ".conv_reduce.weight", DMM_T_CONV, {g.nf[j], g.nin[j], 1, 1});
+    tb.bn(p + ".norm1", g.nf[j]);
+    tb.add("decoder.Transposed_Convolution_" + std::to_string(j + 1) + ".weight", DMM_T_CONVT, {g.nf[j], g.nf[j], 3, 3});
+  }
+  const int nfl = g.nf[g.nb - 1], hin = nfl + g.s1 + g.s2;
+  tb.bn("dec_out_to_heat_maps.norm0", hin);
+  tb.add("dec_out_to_heat_maps.refine0.weight", DMM_T_CONV, {nfl / 2, hin, 3, 3});
+  tb.bn("dec_out_to_heat_maps.norm1", nfl / 2);
+  tb.add("dec_out_to_heat_maps.refine1.weight", DMM_T_CONV, {g.nc, nfl / 2, 5, 5});
+  if (g.fusion == 2) {
+    encoder_table(tb, "stream_2_features", g, g.s2, g.cbb - 1);
+    const int c = g.cin[g.cbb - 1];
+    tb.bn("concat_module.norm", 2 * c);
+    tb.add("concat_module.conv.weight", DMM_T_CONV, {c, 2 * c, 1, 1});
+  }
+  np = tb.np;
+  nbuf = tb.nb;
+}
+
+// ------------------------------------------------------------------------------------------------ builder
+namespace {
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes, size_t align = 256) {
+    off = (off + align - 1) / align * align;
+    const size_t o = off;
+    off += bytes;
+    return o;
+  }
+};
+
+struct Buf {
+  int B, H, W, ld;
+  uint8_t* x = nullptr;   // activations (T)
+  uint8_t* g = nullptr;   // raw gradient (T), same layout
+  double* ssum = nullptr; // per-channel sum / sum^2 of x
+  double* ssq = nullptr;
+  float* q = nullptr;     // deferred BN-backward correction of g
+  float* r = nullptr;
+  bool ginit = false;
+};
+
+struct BnRange { int buf, ch0, c0, n; double count, count_unb; bool want_qr; };
+struct Bn {
+  int C;
+  float *gamma, *beta, *rm, *rv, *dgamma, *dbeta;
+  float *scale, *shift, *mean, *invstd;
+  double *red1, *red2;
+  std::vector<BnRange> ranges;
+};
+
+enum DgradKind { DG_NONE = 0, DG_FLIP, DG_POOL2, DG_CONVT, DG_UP2 };
+
+struct SegRec {
+  int buf, ch0, C /*storage channels*/, Cw /*master channels*/, koff, mode, istride;
+  int bn, bn_c0;
+  int dgrad;
+};
+struct PhaseRec { int py, px; std::vector<Tap> taps; int pack; };
+struct ConvRec {
+  std::string wname;
+  bool transposed;
+  int N, Kin, R, S, pad;
+  int B, Ho, Wo;
+  int nseg;
+  SegRec seg[2];
+  int obuf, och0, ostride;
+  int epi;
+  bool stats;
+  std::vector<PhaseRec> phases;
+  int dpack[2];
+};
+struct PoolRec { int y0buf, bn, obuf, och0; uint8_t* argmax; int C; };
+struct Rec { int type; int idx; };  // 0 conv, 1 pool
+
+struct Builder {
+  dmm_plan& P;
+  const dmm_model_desc& d;
+  Geo g;
+  const int dtype, esz, SLOT, BK;
+  const bool sizing;
+  uint8_t *zbase, *wbase;
+  Bump Z, W;
+  std::map<std::string, const TensorInfo*> tmap;
+  std::vector<Buf> bufs;
+  std::vector<Bn> bns;
+  std::vector<ConvRec> convs;
+  std::vector<PoolRec> pools;
+  std::vector<Rec> recs;
+  std::vector<Op>* ops = nullptr;
+  bool training = true;
+  int in1 = -1, in2 = -1, inH = -1, dl = -1;
+  double flops = 0;
+
+  Builder(dmm_plan& p, bool sizing_, uint8_t* ws)
+      : P(p), d(p.desc), g(p.desc), dtype(p.desc.dtype), esz((int)dtype_size(p.desc.dtype)), SLOT(16 / esz), BK(4 * (16 / esz)),
+        sizing(sizing_) {
+    zbase = ws;
+    wbase = sizing ? nullptr : ws + ((p.zero_bytes + 255) / 256 * 256);
+    for (auto& t : P.tensors) tmap[t.name] = &t;
+  }
+
+  template <typename U> U* zptr(size_t n) { return (U*)((uintptr_t)zbase + Z.take(n * sizeof(U))); }
+  template <typename U> U* wptr(size_t n) { return (U*)((uintptr_t)wbase + W.take(n * sizeof(U))); }
+  int rup(int v, int m) const { return (v + m - 1) / m * m; }
+
+  const TensorInfo& T(const std::string& n) {
+    auto it = tmap.find(n);
+    if (it == tmap.end()) throw std::runtime_error("unknown tensor " + n);
+    return *it->second;
+  }
+
+  int new_buf(int B, int H, int W_, int ld, bool grad, bool stats) {
+    Buf b;
+    b.B = B; b.H = H; b.W = W_; b.ld = ld;
+    const size_t n = (size_t)B * H * W_ * ld;
+    b.x = wptr<uint8_t>(n * esz);
+    if (grad) b.g = wptr<uint8_t>(n * esz);
+    if (stats) { b.ssum = zptr<double>(ld); b.ssq = zptr<double>(ld); }
+    if (grad) { b.q = zptr<float>(ld + 8); b.r = zptr<float>(ld + 8); }
+    bufs.push_back(b);
+    return (int)bufs.size() - 1;
+  }
+
+  int new_bn(const std::string& prefix, int C) {
+    Bn b;
+    b.C = C;
+    const TensorInfo &w = T(prefix + ".weight"), &bi = T(prefix + ".bias"), &rm = T(prefix + ".running_mean"),
+                     &rv = T(prefix + ".running_var");
+    b.gamma = P.params + w.off; b.beta = P.params + bi.off;
+    b.dgamma = P.grads + w.off; b.dbeta = P.grads + bi.off;
+    b.rm = P.buffers + rm.off; b.rv = P.buffers + rv.off;
+    const int cp = rup(C, 8) + 8;
+    b.scale = wptr<float>(cp); b.shift = wptr<float>(cp); b.mean = wptr<float>(cp); b.invstd = wptr<float>(cp);
+    b.red1 = zptr<double>(cp); b.red2 = zptr<double>(cp);
+    bns.push_back(b);
+    return (int)bns.size() - 1;
+  }
+  void bn_range(int bn, int buf, int ch0, int c0, int n, double unb_mult = 1.0, bool want_qr = true) {
+    const Buf& b = bufs[buf];
+    const double cnt = (double)b.B * b.H * b.W;
+    bns[bn].ranges.push_back({buf, ch0, c0, n, cnt, cnt * unb_mult, want_qr});
+  }
+
+  // -------------------------------------------------------------------------------- pack registry
+  int add_pack(const ConvRec& c, const std::vector<Tap>& taps, bool dgrad_seg, int seg_index) {
+    PackDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    const TensorInfo& w = T(c.wname);
+    pd.w = P.params + w.off;
+    const long long RS = (long long)c.R * c.S;
+    long long base_off = 0;
+    if (!dgrad_seg) {
+      pd.N = c.N;
+      pd.nseg = c.nseg;
+      if (!c.transposed) { pd.sn = c.Kin * RS; pd.sk = RS; }
+      else { pd.sn = RS; pd.sk = (long long)c.N * RS; }
+      for (int s = 0; s < c.nseg; ++s) fill_pack_seg(pd.seg[s], taps, c.seg[s].Cw, c.seg[s].C, c.seg[s].koff, BK);
+      pd.gw = P.grads + w.off;
+    } else {
+      const SegRec& sr = c.seg[seg_index];
+      pd.N = sr.Cw;
+      pd.nseg = 1;
+      if (!c.transposed) { pd.sn = RS; pd.sk = c.Kin * RS; base_off = sr.koff * RS; }
+      else { pd.sn = (long long)c.N * RS; pd.sk = RS; }
+      const int kc = rup(c.N, 8);
+      fill_pack_seg(pd.seg[0], taps, c.N, kc, 0, BK);
+    }
+    pd.st = 1;
+    pd.w += base_off;
+    pd.Npad = rup(dgrad_seg ? c.seg[seg_index].C : c.N, 32);
+    int chunks = 0;
+    for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
+    const size_t elems = (size_t)chunks * pd.Npad * BK;
+    pd.dst = wptr<uint8_t>(elems * esz);
+    if (!dgrad_seg) pd.dpack = zptr<float>(elems);
+    if (!dgrad_seg && pd.gw) pd.gw += 0;
+    P.packs.push_back(pd);
+    return (int)P.packs.size() - 1;
+  }
+
+  // -------------------------------------------------------------------------------- op emission
+  Op& push(int kind) {
+    ops->emplace_back();
+    ops->back().kind = kind;
+    return ops->back();
+  }
+  const uint8_t* xat(int buf, int ch) const { return bufs[buf].x + (size_t)ch * esz; }
+  uint8_t* gat(int buf, int ch) const { return bufs[buf].g ? bufs[buf].g + (size_t)ch * esz : nullptr; }
+
+  void emit_bn_finalize(int bn) {
+    Bn& b = bns[bn];
+    for (auto& rg : b.ranges) {
+      Op& o = push(OP_BNFIN);
+      BnFinalizeArgs& a = o.bf;
+      const Buf& sb = bufs[rg.buf];
+      a.sum = sb.ssum ? sb.ssum + rg.ch0 : nullptr;
+      a.sq = sb.ssq ? sb.ssq + rg.ch0 : nullptr;
+      a.count = rg.count;
+      a.count_unbiased = rg.count_unb;
+      a.gamma = b.gamma + rg.c0; a.beta = b.beta + rg.c0;
+      a.running_mean = b.rm + rg.c0; a.running_var = b.rv + rg.c0;
+      a.scale = b.scale + rg.c0; a.shift = b.shift + rg.c0; a.mean = b.mean + rg.c0; a.invstd = b.invstd + rg.c0;
+      a.C = rg.n;
+      a.training = training ? 1 : 0;
+      a.momentum = d.bn_momentum;
+      a.eps = d.bn_eps;
+    }
+  }
+
+  void fill_fwd_seg(Seg& s, const SegRec& sr, const std::vector<Tap>& taps) {
+    memset(&s, 0, sizeof(s));
+    const Buf& b = bufs[sr.buf];
+    s.src = xat(sr.buf, sr.ch0);
+    s.ld = b.ld;
+    s.Hs = b.H; s.Ws = b.W;
+    s.C = sr.C; s.Cpad = sr.C;
+    s.mode = sr.mode;
+    s.istride = sr.istride;
+    if (sr.bn >= 0) { s.scale = bns[sr.bn].scale + sr.bn_c0; s.shift = bns[sr.bn].shift + sr.bn_c0; }
+    fill_seg_taps(s, taps, BK);
+  }
+
+  void emit_conv_fwd(ConvRec& c) {
+    int done[2] = {-1, -1};
+    for (int s = 0; s < c.nseg; ++s) {
+      const int bn = c.seg[s].bn;
+      if (bn < 0 || bn == done[0]) continue;
+      emit_bn_finalize(bn);
+      done[s] = bn;
+    }
+    const Buf& ob = bufs[c.obuf];
+    for (auto& ph : c.phases) {
+      Op& o = push(OP_IGEMM);
+      o.epi = c.epi;
+      ConvArgs& a = o.c;
+      memset(&a, 0, sizeof(a));
+      a.nseg = c.nseg;
+      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], ph.taps);
+      a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
+      const PackDesc& pd = P.packs[ph.pack];
+      a.wpack = pd.dst;
+      a.N = c.N; a.Npad = pd.Npad;
+      a.out = (void*)xat(c.obuf, c.och0);
+      a.ldo = ob.ld; a.Hout = ob.H; a.Wout = ob.W;
+      a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
+      if (c.stats && ob.ssum) { a.stat_sum = ob.ssum + c.och0; a.stat_sq = ob.ssq + c.och0; }
+      if (c.epi == EPI_LOGITS) {
+        if (training) P.logits_op_train = (int)ops->size() - 1; else P.logits_op_eval = (int)ops->size() - 1;
+      }
+    }
+  }
+
+  void fill_grad_seg(Seg& s, int buf, int ch0, int C, const std::vector<Tap>& taps, int istride) {
+    memset(&s, 0, sizeof(s));
+    const Buf& b = bufs[buf];
+    s.src = gat(buf, ch0);
+    s.ld = b.ld;
+    s.Hs = b.H; s.Ws = b.W;
+    s.C = C; s.Cpad = C;
+    s.mode = G_PLAIN;
+    s.istride = istride;
+    if (b.q) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; }
+    fill_seg_taps(s, taps, BK);
+  }
+
+  void emit_bn_bwd_finalize(int bn) {
+    Bn& b = bns[bn];
+    for (auto& rg : b.ranges) {
+      Op& o = push(OP_BNBWD);
+      BnBwdFinalizeArgs& a = o.bb;
+      a.red1 = b.red1 + rg.c0; a.red2 = b.red2 + rg.c0;
+      a.mean = b.mean + rg.c0; a.invstd = b.invstd + rg.c0; a.scale = b.scale + rg.c0;
+      a.dgamma = b.dgamma + rg.c0; a.dbeta = b.dbeta + rg.c0;
+      const Buf& sb = bufs[rg.buf];
+      a.q = (rg.want_qr && sb.q) ? sb.q + rg.ch0 : nullptr;
+      a.r = (rg.want_qr && sb.r) ? sb.r + rg.ch0 : nullptr;
+      a.count = rg.count;
+      a.grad_scale = 1.0f / d.loss_scale;
+      a.C = rg.n;
+    }
+  }
+
+  void emit_conv_bwd(ConvRec& c) {
+    const Buf& ob = bufs[c.obuf];
+    const int Nst = rup(c.N, 8);  // storage channels of the output gradient
+    // ---- weight gradient, one launch per phase ----
+    for (auto& ph : c.phases) {
+      Op& o = push(OP_WGRAD);
+      WgradArgs& a = o.w;
+      memset(&a, 0, sizeof(a));
+      a.nseg = c.nseg;
+      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], ph.taps);
+      a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
+      a.dy.src = gat(c.obuf, c.och0);
+      a.dy.ld = ob.ld;
+      if (ob.q) { a.dy.src2 = xat(c.obuf, c.och0); a.dy.ld2 = ob.ld; a.dy.q = ob.q + c.och0; a.dy.r = ob.r + c.och0; }
+      const PackDesc& pd = P.packs[ph.pack];
+      a.N = c.N; a.Npad = pd.Npad;
+      a.Hout = ob.H; a.Wout = ob.W; a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
+      a.dpack = (float*)pd.dpack;
+    }
+    // ---- data gradients with fused BN+ReLU backward ----
+    for (int s = 0; s < c.nseg; ++s) {
+      SegRec& sr = c.seg[s];
+      if (sr.dgrad == DG_NONE) continue;
+      Buf& sb = bufs[sr.buf];
+      std::vector<Tap> taps;
+      int istride = 1, rB = sb.B, rH = sb.H, rW = sb.W, pool2 = 0, ostride = 1;
+      switch (sr.dgrad) {
+        case DG_FLIP: taps = taps_conv_dgrad(c.R, c.S, c.pad); break;
+        case DG_POOL2: taps = taps_conv(1, 1, 0); rH = sb.H / 2; rW = sb.W / 2; pool2 = 1; ostride = 2; break;
+        case DG_CONVT: taps = taps_convT_dgrad(); istride = 2; break;
+        case DG_UP2: taps = taps_up2_merged_dgrad(); istride = 2; break;
+      }
+      Op& o = push(OP_IGEMM);
+      o.epi = EPI_BNBWD;
+      ConvArgs& a = o.c;
+      memset(&a, 0, sizeof(a));
+      a.nseg = 1;
+      fill_grad_seg(a.seg[0], c.obuf, c.och0, Nst, taps, istride);
+      a.B = rB; a.Ho = rH; a.Wo = rW; a.M = rB * rH * rW;
+      const PackDesc& pd = P.packs[c.dpack[s]];
+      a.wpack = pd.dst;
+      a.N = sr.C; a.Npad = pd.Npad;
+      a.out = gat(sr.buf, sr.ch0);
+      a.ldo = sb.ld; a.Hout = sb.H; a.Wout = sb.W; a.ostride = ostride; a.py = 0; a.px = 0;
+      a.bx = xat(sr.buf, sr.ch0);
+      a.ldbx = sb.ld;
+      const Bn& bn = bns[sr.bn];
+      a.bscale = bn.scale + sr.bn_c0; a.bshift = bn.shift + sr.bn_c0;
+      a.red1 = bn.red1 + sr.bn_c0; a.red2 = bn.red2 + sr.bn_c0;
+      a.accumulate = sb.ginit ? 1 : 0;
+      a.pool2 = pool2;
+      sb.ginit = true;
+    }
+    int done = -1;
+    for (int s = 0; s < c.nseg; ++s) {
+      const int bn = c.seg[s].bn;
+      if (bn < 0 || bn == done || c.seg[s].dgrad == DG_NONE) continue;
+      emit_bn_bwd_finalize(bn);
+      done = bn;
+    }
+  }
+
+  void emit_pool_fwd(PoolRec& p) {
+    emit_bn_finalize(p.bn);
+    Op& o = push(OP_POOL);
+    MaxpoolArgs& a = o.mp;
+    const Buf &yb = bufs[p.y0buf], &ob = bufs[p.obuf];
+    a.y0 = yb.x; a.ld0 = yb.ld; a.H0 = yb.H; a.W0 = yb.W; a.B = yb.B; a.C = p.C;
+    a.scale = bns[p.bn].scale; a.shift = bns[p.bn].shift;
+    a.out = (void*)xat(p.obuf, p.och0); a.ldo = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
+    a.argmax = p.argmax;
+    a.stat_sum = ob.ssum + p.och0; a.stat_sq = ob.ssq + p.och0;
+  }
+  void emit_pool_bwd(PoolRec& p) {
+    Op& o = push(OP_POOLBWD);
+    MaxpoolBwdArgs& a = o.mpb;
+    Buf &yb = bufs[p.y0buf];
+    const Buf &ob = bufs[p.obuf];
+    a.y0 = yb.x; a.ld0 = yb.ld; a.H0 = yb.H; a.W0 = yb.W; a.B = yb.B; a.C = p.C;
+    a.scale = bns[p.bn].scale; a.shift = bns[p.bn].shift;
+    a.gpool = gat(p.obuf, p.och0); a.xpool = xat(p.obuf, p.och0);
+    a.q = ob.q + p.och0; a.r = ob.r + p.och0;
+    a.ldg = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
+    a.argmax = p.argmax;
+    a.gy0 = yb.g;
+    a.red1 = bns[p.bn].red1; a.red2 = bns[p.bn].red2;
+    yb.ginit = true;
+    emit_bn_bwd_finalize(p.bn);
+  }
+
+  // -------------------------------------------------------------------------------- layer records
+  ConvRec& new_conv(const std::string& wname, bool transposed, int N, int Kin, int R, int S, int pad) {
+    ConvRec c;
+    c.wname = wname; c.transposed = transposed; c.N = N; c.Kin = Kin; c.R = R; c.S = S; c.pad = pad;
+    c.nseg = 1; c.ostride = 1; c.epi = EPI_STORE; c.stats = true;
+    c.dpack[0] = c.dpack[1] = -1;
+    memset(c.seg, 0, sizeof(c.seg));
+    c.seg[0].bn = c.seg[1].bn = -1;
+    convs.push_back(c);
+    recs.push_back({0, (int)convs.size() - 1});
+    return convs.back();
+  }
+  void finish_conv(ConvRec& c) {
+    // forward packs (one per phase) and dgrad packs (one per segment that needs a data gradient)
+    for (auto& ph : c.phases) ph.pack = add_pack(c, ph.taps, false, 0);
+    for (int s = 0; s < c.nseg; ++s) {
+      std::vector<Tap> t;
+      switch (c.seg[s].dgrad) {
+        case DG_FLIP: t = taps_conv_dgrad(c.R, c.S, c.pad); break;
+        case DG_POOL2: t = taps_conv(1, 1, 0); break;
+        case DG_CONVT: t = taps_convT_dgrad(); break;
+        case DG_UP2: t = taps_up2_merged_dgrad(); break;
+        default: continue;
+      }
+      c.dpack[s] = add_pack(c, t, true, s);
+    }
+    // FLOPs (2*MACs) in the reference's formulation
+    const double px = (double)c.B * c.Ho * c.Wo * (c.seg[0].mode == G_POOL2 ? 4.0 : 1.0);
+    if (c.transposed) flops += 2.0 * px * c.N * c.Kin * 9.0;
+    else flops += 2.0 * px * c.N * c.Kin * c.R * c.S;
+  }
+  void set_seg(ConvRec& c, int s, int buf, int ch0, int Cw, int koff, int mode, int istride, int bn, int bn_c0, int dgrad) {
+    SegRec& sr = c.seg[s];
+    sr.buf = buf; sr.ch0 = ch0; sr.Cw = Cw; sr.C = rup(Cw, 8); sr.koff = koff; sr.mode = mode; sr.istride = istride;
+    sr.bn = bn; sr.bn_c0 = bn_c0; sr.dgrad = dgrad;
+  }
+
+  // stem: conv0 (7x7 s2) -> norm0 -> relu0 -> pool0, output into `obuf` channels [och0, och0+nif)
+  void stem(const std::string& p, int inbuf, int in_ch, int obuf, int och0) {
+    const Buf ib = bufs[inbuf];  // by value: new_buf() may reallocate `bufs`
+    const int y0 = new_buf(ib.B, ib.H / 2, ib.W / 2, g.nif, true, true);
+    ConvRec& c = new_conv(p + ".conv0.weight", false, g.nif, in_ch, 7, 7, 3);
+    set_seg(c, 0, inbuf, 0, in_ch, 0, G_PLAIN, 2, -1, 0, DG_NONE);
+    c.B = ib.B; c.Ho = ib.H / 2; c.Wo = ib.W / 2;
+    c.obuf = y0; c.och0 = 0;
+    c.phases.push_back({0, 0, taps_conv(7, 7, 3), -1});
+    finish_conv(c);
+    PoolRec pr;
+    pr.y0buf = y0;
+    pr.bn = new_bn(p + ".norm0", g.nif);
+    bn_range(pr.bn, y0, 0, 0, g.nif);
+    pr.obuf = obuf; pr.och0 = och0; pr.C = g.nif;
+    pr.argmax = wptr<uint8_t>((size_t)ib.B * (ib.H / 4) * (ib.W / 4) * g.nif);
+    pools.push_back(pr);
+    recs.push_back({1, (int)pools.size() - 1});
+  }
+
+  void dense_block(const std::string& p, int xb, int base, int b) {
+    const Buf X = bufs[xb];  // by value: new_buf() may reallocate `bufs`
+    const int bw = g.bs * g.k;
+    for (int l = 0; l < g.L[b]; ++l) {
+      const std::string q = p + ".denselayer" + std::to_string(l + 1);
+      const int K = g.cin[b] + l * g.k;
+      const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true);
+      const int n1 = new_bn(q + ".norm1", K);
+      bn_range(n1, xb, base, 0, K);
+      {
+        ConvRec& c = new_conv(q + ".conv1.weight", false, bw, K, 1, 1, 0);
+        set_seg(c, 0, xb, base, K, 0, G_PLAIN, 1, n1, 0, DG_FLIP);
+        c.B = X.B; c.Ho = X.H; c.Wo = X.W; c.obuf = y1; c.och0 = 0;
+        c.phases.push_back({0, 0, taps_conv(1, 1, 0), -1});
+        finish_conv(c);
+      }
+      const int n2 = new_bn(q + ".norm2", bw);
+      bn_range(n2, y1, 0, 0, bw);
+      {
+        ConvRec& c = new_conv(q + ".conv2.weight", false, g.k, bw, 3, 3, 1);
+        set_seg(c, 0, y1, 0, bw, 0, G_PLAIN, 1, n2, 0, DG_FLIP);
+        c.B = X.B; c.Ho = X.H; c.Wo = X.W; c.obuf = xb; c.och0 = base + K;
+        c.phases.push_back({0, 0, taps_conv(3, 3, 1), -1});
+        finish_conv(c);
+      }
+    }
+  }
+
+  void transition(const std::string& p, int xb, int base, int C, int obuf, int och0) {
+    const Buf X = bufs[xb];
+    const int n = new_bn(p + ".norm", C);
+    bn_range(n, xb, base, 0, C);
+    ConvRec& c = new_conv(p + ".conv.weight", false, C / 2, C, 1, 1, 0);
+    set_seg(c, 0, xb, base, C, 0, G_POOL2, 1, n, 0, DG_POOL2);
+    c.B = X.B; c.Ho = X.H / 2; c.Wo = X.W / 2; c.obuf = obuf; c.och0 = och0;
+    c.phases.push_back({0, 0, taps_conv(1, 1, 0), -1});
+    finish_conv(c);
+  }
+
+  void build() {
+    const int B = d.batch, H = d.height, Wd = d.width;
+    if (H % 32 || Wd % 32 || H <= 0 || Wd <= 0) throw std::domain_error("spatial size must be a multiple of 32");
+    if (g.k % 8 || g.nif % 8 || (g.bs * g.k) % 8) throw std::invalid_argument("channel counts must be multiples of 8");
+    if (g.s1 + g.s2 > 8 || g.s1 < 1) throw std::invalid_argument("at most 8 raw input channels are supported");
+    for (int b = 0; b + 1 < g.nb; ++b)
+      if (g.cout[b] % 16) throw std::invalid_argument("block widths must be multiples of 16");
+    if (g.nc > 8) throw std::invalid_argument("num_classes > 8 unsupported");
+
+    // raw inputs (NHWC8).  inH = what the head concatenates (both streams in early / mid fusion).
+    in1 = new_buf(B, H, Wd, 8, g.fusion != 2, true);
+    if (g.fusion == 2) { in2 = new_buf(B, H, Wd, 8, false, false); inH = new_buf(B, H, Wd, 8, true, true); }
+    else inH = in1;
+
+    // block buffers of stream 1: [decoder ConvTranspose output | block channels]
+    std::vector<int> X(g.nb), base(g.nb);
+    for (int b = 0; b < g.nb; ++b) {
+      base[b] = (b < g.nb - 1) ? g.cout[b] : 0;
+      X[b] = new_buf(B, H >> (2 + b), Wd >> (2 + b), base[b] + g.cout[b], true, true);
+    }
+    int F = -1;
+    const int cbb = g.cbb;
+    if (g.fusion == 2) {
+      F = new_buf(B, H >> (1 + cbb), Wd >> (1 + cbb), 2 * g.cin[cbb - 1], true, true);
+      std::vector<int> X2(cbb - 1);
+      for (int b = 0; b < cbb - 1; ++b) X2[b] = new_buf(B, H >> (2 + b), Wd >> (2 + b), g.cout[b], true, true);
+      stem("stream_2_features", in2, g.s2, X2[0], 0);
+      for (int b = 0; b < cbb - 1; ++b) {
+        dense_block("stream_2_features.denseblock" + std::to_string(b + 1), X2[b], 0, b);
+        const bool last = b == cbb - 2;
+        transition("stream_2_features.transition" + std::to_string(b + 1), X2[b], 0, g.cout[b], last ? F : X2[b + 1],
+                   last ? g.cin[cbb - 1] : 0);
+      }
+    }
+    stem("features", in1, g.net_in, X[0], base[0]);
+    for (int b = 0; b < g.nb; ++b) {
+      if (g.fusion == 2 && b == cbb - 1) {
+        const int C = g.cin[b];
+        const int n = new_bn("concat_module.norm", 2 * C);
+        bn_range(n, F, 0, 0, 2 * C);
+        ConvRec& c = new_conv("concat_module.conv.weight", false, C, 2 * C, 1, 1, 0);
+        set_seg(c, 0, F, 0, 2 * C, 0, G_PLAIN, 1, n, 0, DG_FLIP);
+        c.B = B; c.Ho = bufs[F].H; c.Wo = bufs[F].W; c.obuf = X[b]; c.och0 = base[b];
+        c.phases.push_back({0, 0, taps_conv(1, 1, 0), -1});
+        finish_conv(c);
+      }
+      dense_block("features.denseblock" + std::to_string(b + 1), X[b], base[b], b);
+      if (b < g.nb - 1) {
+        const bool toF = g.fusion == 2 && b == cbb - 2;
+        transition("features.transition" + std::to_string(b + 1), X[b], base[b], g.cout[b], toF ? F : X[b + 1],
+                   toF ? 0 : base[b + 1]);
+      }
+    }
+    // decoder
+    int U = -1;
+    for (int j = 0; j < g.nb; ++j) {
+      const std::string p = "decoder.Transposed_Convolution_Sequence_" + std::to_string(j + 1);
+      // stage j reads block nb-1 (j = 0) or the full [ConvTranspose_{j-1} | block nb-1-j] buffer
+      const int inb = X[g.nb - 1 - j];
+      const Buf I = bufs[inb];  // by value: new_buf() may reallocate `bufs`
+      const int nin = g.nin[j], nf = g.nf[j];
+      if (I.ld != nin) throw std::runtime_error("decoder width mismatch");
+      const int n0 = new_bn(p + ".norm0", nin);
+      bn_range(n0, inb, 0, 0, nin);
+      const int Rb = new_buf(I.B, I.H, I.W, nf, true, true);
+      {
+        ConvRec& c = new_conv(p + ".conv_reduce.weight", false, nf, nin, 1, 1, 0);
+        set_seg(c, 0, inb, 0, nin, 0, G_PLAIN, 1, n0, 0, DG_FLIP);
+        c.B = I.B; c.Ho = I.H; c.Wo = I.W; c.obuf = Rb; c.och0 = 0;
+        c.phases.push_back({0, 0, taps_conv(1, 1, 0), -1});
+        finish_conv(c);
+      }
+      const int n1 = new_bn(p + ".norm1", nf);
+      bn_range(n1, Rb, 0, 0, nf);
+      int ob;
+      if (j < g.nb - 1) ob = X[g.nb - 2 - j];
+      else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true);
+      if (bufs[ob].H != 2 * I.H) throw std::runtime_error("decoder size mismatch");
+      {
+        ConvRec& c = new_conv("decoder.Transposed_Convolution_" + std::to_string(j + 1) + ".weight", true, nf, nf, 3, 3, 1);
+        set_seg(c, 0, Rb, 0, nf, 0, G_PLAIN, 1, n1, 0, DG_CONVT);
+        c.B = I.B; c.Ho = I.H; c.Wo = I.W; c.obuf = ob; c.och0 = 0; c.ostride = 2;
+        for (int py = 0; py < 2; ++py)
+          for (int px = 0; px < 2; ++px) c.phases.push_back({py, px, taps_convT_phase(py, px), -1});
+        finish_conv(c);
+      }
+    }
+    // head
+    const int nfl = g.nf[g.nb - 1], raw = g.s1 + g.s2;
+    const int hn0 = new_bn("dec_out_to_heat_maps.norm0", nfl + raw);
+    bn_range(hn0, U, 0, 0, nfl, 4.0);
+    bn_range(hn0, inH, 0, nfl, raw, 1.0, false);
+    const int YR = new_buf(B, H, Wd, nfl / 2, true, true);
+    {
+      ConvRec& c = new_conv("dec_out_to_heat_maps.refine0.weight", false, nfl / 2, nfl + raw, 3, 3, 1);
+      c.nseg = 2;
+      set_seg(c, 0, U, 0, nfl, 0, G_UP2, 1, hn0, 0, DG_UP2);
+      set_seg(c, 1, inH, 0, raw, nfl, G_PLAIN, 1, hn0, nfl, DG_FLIP);
+      c.B = B; c.Ho = H; c.Wo = Wd; c.obuf = YR; c.och0 = 0;
+      c.phases.push_back({0, 0, taps_conv(3, 3, 1), -1});
+      finish_conv(c);
+    }
+    const int hn1 = new_bn("dec_out_to_heat_maps.norm1", nfl / 2);
+    bn_range(hn1, YR, 0, 0, nfl / 2);
+    dl = new_buf(B, H, Wd, 8, false, false);  // x = d(loss)/d(logit) in NHWC8; used as a gradient source only
+    bufs[dl].g = bufs[dl].x;
+    {
+      ConvRec& c = new_conv("dec_out_to_heat_maps.refine1.weight", false, g.nc, nfl / 2, 5, 5, 2);
+      set_seg(c, 0, YR, 0, nfl / 2, 0, G_PLAIN, 1, hn1, 0, DG_FLIP);
+      c.B = B; c.Ho = H; c.Wo = Wd; c.obuf = dl; c.och0 = 0;
+      c.epi = EPI_LOGITS; c.stats = false;
+      c.phases.push_back({0, 0, taps_conv(5, 5, 2), -1});
+      finish_conv(c);
+    }
+  }
+
+  // -------------------------------------------------------------------------------- launch lists
+  void emit_convert(std::vector<int>& idx) {
+    auto one = [&](int buf, int c1, int c2, int which) {
+      Op& o = push(OP_CONVERT);
+      ConvertArgs& a = o.cv;
+      memset(&a, 0, sizeof(a));
+      a.C1 = c1; a.C2 = c2;
+      a.scale = 1.0f;
+      a.dst = bufs[buf].x;
+      a.B = bufs[buf].B; a.H = bufs[buf].H; a.W = bufs[buf].W;
+      a.stat_sum = bufs[buf].ssum; a.stat_sq = bufs[buf].ssq;
+      o.epi = which;  // 0: (s1), 1: (s1,s2), 2: (s2)
+      idx.push_back((int)ops->size() - 1);
+    };
+    if (g.fusion == 0) one(in1, g.s1, 0, 0);
+    else if (g.fusion == 1) one(in1, g.s1, g.s2, 1);
+    else { one(in1, g.s1, 0, 0); one(in2, g.s2, 0, 2); one(inH, g.s1, g.s2, 1); }
+  }
+
+  void emit_pack_op(int kind) {
+    Op& o = push(kind);
+    o.pk.descs = pack_dev;
+    o.pk.prefix = prefix_dev;
+    o.pk.ndesc = (int)P.packs.size();
+    o.pk.total_rows = total_rows;
+    o.pk.grad_scale = 1.0f / d.loss_scale;
+  }
+
+  PackDesc* pack_dev = nullptr;
+  int* prefix_dev = nullptr;
+  int total_rows = 0;
+
+  void emit_all() {
+    // pack tables live in the workspace
+    P.pack_prefix.clear();
+    total_rows = 0;
+    for (auto& pd : P.packs) {
+      P.pack_prefix.push_back(total_rows);
+      int chunks = 0;
+      for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
+      total_rows += chunks * pd.Npad;
+    }
+    pack_dev = wptr<PackDesc>(P.packs.size());
+    prefix_dev = wptr<int>(P.packs.size());
+    P.metrics_bytes = (size_t)(2 * g.nc + (size_t)d.batch * 2 * g.nc) * sizeof(double);
+    P.metrics = zptr<double>(P.metrics_bytes / sizeof(double));
+
+    std::vector<Op> dummy;
+    // ---- training forward ----
+    ops = sizing ? &dummy : &P.fwd_train;
+    ops->clear();
+    training = true;
+    { Op& o = push(OP_MEMSET); o.ms.p = zbase; o.ms.bytes = 0; /* patched below */ }
+    emit_pack_op(OP_PACK);
+    P.convert_ops_train.clear();
+    emit_convert(P.convert_ops_train);
+    for (auto& r : recs) { if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]); }
+    // ---- eval forward ----
+    ops = sizing ? &dummy : &P.fwd_eval;
+    ops->clear();
+    training = false;
+    emit_pack_op(OP_PACK);
+    P.convert_ops_eval.clear();
+    emit_convert(P.convert_ops_eval);
+    for (auto& r : recs) { if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]); }
+    // ---- loss + backward ----
+    ops = sizing ? &dummy : &P.bwd;
+    ops->clear();
+    training = true;
+    {
+      Op& o = push(OP_BCE);
+      BceArgs& a = o.bce;
+      memset(&a, 0, sizeof(a));
+      a.dlogits = bufs[dl].x;
+      a.out = P.metrics;
+      a.B = d.batch; a.NC = g.nc; a.H = d.height; a.W = d.width;
+      a.thr = d.iou_threshold; a.loss_scale = d.loss_scale;
+      P.bce_op = (int)ops->size() - 1;
+      P.bce_only = o;
+      P.bce_only.bce.dlogits = nullptr;
+    }
+    for (auto& b : bufs) b.ginit = false;
+    for (int i = (int)recs.size() - 1; i >= 0; --i) {
+      if (recs[i].type == 0) emit_conv_bwd(convs[recs[i].idx]); else emit_pool_bwd(pools[recs[i].idx]);
+    }
+    emit_pack_op(OP_UNPACK);
+  }
+};
+
+}  // namespace
+}  // namespace dmm
+
+// ---------------------------------------------------------------------------------------------------- C-level plan API
+using namespace dmm;
+
+void plan_build_tables(dmm_plan* p) {
+  build_tensor_table(p->desc, p->tensors, p->nparams, p->nbuf);
+  Builder b(*p, true, nullptr);
+  b.build();
+  b.emit_all();
+  p->zero_bytes = (b.Z.off + 255) / 256 * 256;
+  p->main_bytes = (b.W.off + 255) / 256 * 256;
+  p->fwd_flops = b.flops;
+  p->packs.clear();
+}
+
+void plan_bind(dmm_plan* p, void* ws) {
+  p->packs.clear();
+  p->fwd_train.clear(); p->fwd_eval.clear(); p->bwd.clear();
+  Builder b(*p, false, (uint8_t*)ws);
+  b.build();
+  b.emit_all();
+  // the training forward starts by zeroing the whole accumulator region
+  p->fwd_train[0].ms.p = ws;
+  p->fwd_train[0].ms.bytes = p->zero_bytes;
+  p->ws = ws;
+  // zero everything once: padding lanes of scale/shift tables and NHWC8 pad channels must read as 0
+  hipMemset(ws, 0, p->zero_bytes + p->main_bytes);
+  // upload the pack tables
+  hipMemcpy(b.pack_dev, p->packs.data(), p->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+  hipMemcpy(b.prefix_dev, p->pack_prefix.data(), p->pack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);
+}

@@ -1,0 +1,81 @@
+// Host-side plan of the Dense_U_Net_lidar training step: topology -> buffers -> kernel launch list.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/dmmfods_hip.h"
+#include "common.h"
+#include "pointwise.h"
+
+namespace dmm {
+
+struct TensorInfo {
+  std::string name;
+  int kind, ndim;
+  int64_t shape[4];
+  int64_t off;  // elements into the param arena / buffer arena, -1 for num_batches_tracked
+};
+
+struct Tap {
+  int dy, dx;
+  unsigned tapw;  // up to four master tap indices (8 bits each, 0xff = none)
+};
+
+// tap geometry helpers (shared with the single-kernel test entry points)
+std::vector<Tap> taps_conv(int R, int S, int pad);            // forward stride-1/2 conv: (ky-pad, kx-pad)
+std::vector<Tap> taps_conv_dgrad(int R, int S, int pad);      // data gradient of a stride-1 conv: (pad-ky, pad-kx)
+std::vector<Tap> taps_convT_phase(int py, int px);            // ConvTranspose 3x3 s2 p1, output parity (py,px)
+std::vector<Tap> taps_convT_dgrad();                          // stride-2 gather over the output gradient
+std::vector<Tap> taps_up2_merged_dgrad();                     // 3x3 conv over a nearest-x2 source: 4x4 s2 merged taps
+void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK);
+void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK);
+
+enum OpKind { OP_MEMSET = 0, OP_CONVERT, OP_IGEMM, OP_WGRAD, OP_BNFIN, OP_BNBWD, OP_POOL, OP_POOLBWD, OP_BCE, OP_PACK, OP_UNPACK,
+              OP_COPY };
+
+struct MemsetArgs { void* p; size_t bytes; };
+struct CopyArgs { void* dst; const void* src; size_t bytes; };
+struct PackArgs { const PackDesc* descs; const int* prefix; int ndesc, total_rows; float grad_scale; };
+
+struct Op {
+  int kind;
+  int epi;
+  union {
+    MemsetArgs ms;
+    CopyArgs cp;
+    ConvertArgs cv;
+    ConvArgs c;
+    WgradArgs w;
+    BnFinalizeArgs bf;
+    BnBwdFinalizeArgs bb;
+    MaxpoolArgs mp;
+    MaxpoolBwdArgs mpb;
+    BceArgs bce;
+    PackArgs pk;
+  };
+  Op() : kind(0), epi(0) {}
+};
+
+}  // namespace dmm
+
+struct dmm_plan {
+  dmm_model_desc desc;
+  std::vector<dmm::TensorInfo> tensors;
+  int64_t nparams = 0, nbuf = 0;
+  size_t zero_bytes = 0, main_bytes = 0;
+  double fwd_flops = 0;
+  bool bound = false;
+  void* ws = nullptr;
+  float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+  // launch lists (built by bind)
+  std::vector<dmm::Op> fwd_train, fwd_eval, bwd;
+  // indices of ops whose pointers are patched per call
+  std::vector<int> convert_ops_train, convert_ops_eval;
+  int logits_op_train = -1, logits_op_eval = -1;
+  int bce_op = -1, bce_only_valid = 0;
+  dmm::Op bce_only;     // loss + metrics without gradient
+  double* metrics = nullptr;  // device, inside the zero region
+  size_t metrics_bytes = 0;
+  std::vector<dmm::PackDesc> packs;
+  std::vector<int> pack_prefix;
+};

@@ -1,0 +1,126 @@
+// Argument blocks and launchers of the helper kernels (see pointwise.hip) and of the two GEMM kernels.
+#pragma once
+#include "common.h"
+
+namespace dmm {
+
+struct ConvertArgs {
+  const float* src1;  // (B, C1, H, W) fp32
+  const float* src2;  // (B, C2, H, W) fp32 or null
+  int C1, C2;         // C1 + C2 <= 8
+  void* dst;          // T NHWC, 8 channels per pixel, zero padded
+  int B, H, W;
+  double* stat_sum;   // 8 doubles each (nullable)
+  double* stat_sq;
+  float scale;        // multiplies every value (1 for inputs; loss_scale for an external d(loss)/d(logit))
+};
+
+struct BnFinalizeArgs {
+  const double* sum;
+  const double* sq;
+  double count;           // positions the sums were taken over
+  double count_unbiased;  // positions PyTorch's BatchNorm sees (differs for the nearest-upsampled head input)
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* scale;
+  float* shift;
+  float* mean;
+  float* invstd;
+  int C;
+  int training;
+  float momentum, eps;
+};
+
+struct BnBwdFinalizeArgs {
+  const double* red1;  // sum dz
+  const double* red2;  // sum dz*x
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  float* dgamma;
+  float* dbeta;
+  float* q;  // deferred correction accumulators of the normalised tensor (nullable)
+  float* r;
+  double count;      // positions of the normalised tensor
+  float grad_scale;  // 1 / loss_scale
+  int C;
+};
+
+struct MaxpoolArgs {
+  const void* y0;  // (B, H0, W0, ld0) conv0 output
+  int ld0, H0, W0, B, C;
+  const float* scale;
+  const float* shift;
+  void* out;  // (B, Hp, Wp, ldo), pre-offset to the destination channels
+  int ldo, Hp, Wp;
+  unsigned char* argmax;  // (B, Hp, Wp, C)
+  double* stat_sum;
+  double* stat_sq;
+};
+
+struct MaxpoolBwdArgs {
+  const void* y0;
+  int ld0, H0, W0, B, C;
+  const float* scale;
+  const float* shift;
+  const void* gpool;  // raw gradient of the pooled tensor (pre-offset), pixel stride ldg
+  const void* xpool;  // pooled forward tensor (same layout) for the deferred correction
+  const float* q;
+  const float* r;
+  int ldg, Hp, Wp;
+  const unsigned char* argmax;
+  void* gy0;  // (B, H0, W0, ld0): s * dz0
+  double* red1;
+  double* red2;
+};
+
+struct BceArgs {
+  const float* logits;  // (B, NC, H, W) fp32
+  const float* target;
+  void* dlogits;  // T NHWC8: (sigmoid(x) - t) * loss_scale   (nullable)
+  double* out;    // [NC loss | NC equal | B x (NC inter, NC union)]
+  int B, NC, H, W;
+  float thr, loss_scale;
+};
+
+struct AdamArgs {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  size_t n;
+  float beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale;
+};
+
+struct PackSeg {
+  int Creal, Cpad, ntaps, nchunks, koff;
+  unsigned tapw[MAX_TAPS];  // up to four master tap indices per packed tap, 0xff = none
+};
+
+struct PackDesc {
+  const float* w;  // master weights
+  void* dst;       // T packed [chunk][Npad][BK]
+  float* gw;       // master gradient (nullable)
+  const float* dpack;  // fp32 packed gradient (nullable)
+  int N, Npad, nseg;
+  int shared_master;  // several descriptors add into the same master elements
+  long long sn, sk, st;  // master index = n*sn + k*sk + tap*st
+  PackSeg seg[2];
+};
+
+hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st);
+hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st);
+hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st);
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st);
+hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st);
+hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st);
+hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st);
+hipError_t launch_bce_metrics(const BceArgs& a, int dtype, hipStream_t st);
+hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st);
+hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
+                         hipStream_t st);
+
+}  // namespace dmm

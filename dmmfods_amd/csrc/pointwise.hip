@@ -1,0 +1,469 @@
+// Bandwidth-bound helper kernels of the Dense_U_Net_lidar training step (gfx950).
+//   convert_input   : fp32 NCHW streams -> T NHWC8 (+ per-channel sum / sum^2 for the head BatchNorm)
+//   bn_finalize     : batch statistics -> (scale, shift, mean, invstd), running-stat update (momentum .1)
+//   bn_bwd_finalize : (sum dz, sum dz*x) -> dgamma, dbeta and the deferred per-channel correction (q, r)
+//   maxpool_fwd/bwd : 3x3 s2 p1 max pooling fused with the BN+ReLU in front of it (first-max argmax saved)
+//   bce_metrics     : BCE-with-logits (sum reduction), d(loss)/d(logit), IoU / accuracy counts
+//   adam            : flat fused Adam (torch.optim.Adam semantics, amsgrad off)
+//   pack / unpack   : OIHW fp32 master weights <-> K-chunked compute layout [chunk][Npad][BK]
+#include "common.h"
+#include "gather.h"
+#include "pointwise.h"
+
+namespace dmm {
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void convert_input_kernel(ConvertArgs a) {
+  // one thread per pixel; reads are coalesced along x within each NCHW plane
+  __shared__ float red[16];
+  if (threadIdx.x < 16) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t npix = (size_t)a.B * plane;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = p / plane, rem = p - b * plane;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float x = 0.f;
+      if (c < a.C1) x = a.src1[(b * a.C1 + c) * plane + rem];
+      else if (c < a.C1 + a.C2) x = a.src2[(b * a.C2 + (c - a.C1)) * plane + rem];
+      v[c] = x * a.scale;
+    }
+    T* d = (T*)a.dst + p * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const T t = from_f32<T>(v[c]);
+      d[c] = t;
+      const float f = to_f32(t);
+      s1[c] += f;
+      s2[c] = fmaf(f, f, s2[c]);
+    }
+  }
+  if (a.stat_sum == nullptr) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float x = s1[c], y = s2[c];
+    for (int o = 32; o > 0; o >>= 1) { x += __shfl_down(x, o); y += __shfl_down(y, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[c], x); atomicAdd(&red[8 + c], y); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    atomic_add_f64(a.stat_sum + threadIdx.x, (double)red[threadIdx.x]);
+    atomic_add_f64(a.stat_sq + threadIdx.x, (double)red[8 + threadIdx.x]);
+  }
+}
+
+hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st) {
+  const size_t npix = (size_t)a.B * a.H * a.W;
+  int grid = (int)((npix + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == DT_F16) hipLaunchKernelGGL(convert_input_kernel<f16>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(convert_input_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(BnFinalizeArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  float mean, var;
+  if (a.training) {
+    const double m = a.sum[c] / a.count;
+    double v = a.sq[c] / a.count - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m;
+    var = (float)v;
+    const double unb = a.count_unbiased > 1 ? v * (a.count_unbiased / (a.count_unbiased - 1.0)) : v;
+    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+  } else {
+    mean = a.running_mean[c];
+    var = a.running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + a.eps);
+  const float s = a.gamma[c] * invstd;
+  a.scale[c] = s;
+  a.shift[c] = a.beta[c] - mean * s;
+  a.mean[c] = mean;
+  a.invstd[c] = invstd;
+}
+
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + 127) / 128), dim3(128), 0, st, a);
+  return hipGetLastError();
+}
+
+__global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  const double S1 = a.red1[c], S2 = a.red2[c];
+  const double mu = a.mean[c], is = a.invstd[c];
+  const double dotp = (S2 - mu * S1) * is;  // sum dz * xhat
+  a.dgamma[c] = (float)(dotp * a.grad_scale);
+  a.dbeta[c] = (float)(S1 * a.grad_scale);
+  if (a.q != nullptr) {
+    const double s = a.scale[c];
+    const double c1 = S1 / a.count, c2 = dotp / a.count;
+    // contribution of this consumer to d/dx:  s*dz (stored by the dgrad epilogue)  - s*c1 - s*c2*(x-mu)*is
+    a.q[c] += (float)(-s * c1 + s * c2 * mu * is);
+    a.r[c] += (float)(-s * c2 * is);
+  }
+}
+
+hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 127) / 128), dim3(128), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Block-wide per-channel reduction helper: NCV slot columns x (256/NCV) row lanes.
+template <int SLOT>
+__device__ __forceinline__ void block_channel_reduce(float* red, int C, int cbase, const float (&s1)[SLOT],
+                                                     const float (&s2)[SLOT], double* d1, double* d2) {
+  // red: 2*C floats, zeroed and synchronised by the caller
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) {
+    atomicAdd(&red[cbase + i], s1[i]);
+    atomicAdd(&red[C + cbase + i], s2[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomic_add_f64(d1 + c, (double)red[c]);
+    atomic_add_f64(d2 + c, (double)red[C + c]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
+  constexpr int SLOT = TT<T>::SLOT;
+  typedef typename TT<T>::vec V;
+  extern __shared__ float red[];
+  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const int ncv = a.C / SLOT;
+  const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv, rpb = blockDim.x / ncv;
+  const int c = cv * SLOT;
+  float sc[SLOT], sh[SLOT], s1[SLOT], s2[SLOT];
+  load_f32s<SLOT>(a.scale + c, sc);
+  load_f32s<SLOT>(a.shift + c, sh);
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  const int npix = a.B * a.Hp * a.Wp;
+  const T* y0 = (const T*)a.y0;
+  T* out = (T*)a.out;
+  if (rl < rpb) {
+    for (int p = blockIdx.x * rpb + rl; p < npix; p += gridDim.x * rpb) {
+      int b, oy, ox;
+      row_to_byx(p, a.Hp, a.Wp, b, oy, ox);
+      float best[SLOT];
+      int arg[SLOT];
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) { best[i] = -INFINITY; arg[i] = 0; }
+      for (int k = 0; k < 9; ++k) {
+        const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+        if (iy < 0 || ix < 0 || iy >= a.H0 || ix >= a.W0) continue;
+        float f[SLOT];
+        vec_to_f32<T>(*(const V*)(y0 + ((size_t)(b * a.H0 + iy) * a.W0 + ix) * a.ld0 + c), f);
+#pragma unroll
+        for (int i = 0; i < SLOT; ++i) {
+          const float v = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
+          if (v > best[i]) { best[i] = v; arg[i] = k; }
+        }
+      }
+      const V ov = f32_to_vec<T>(best);
+      *(V*)(out + (size_t)p * a.ldo + c) = ov;
+      float r[SLOT];
+      vec_to_f32<T>(ov, r);
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) {
+        a.argmax[(size_t)p * a.C + c + i] = (unsigned char)arg[i];
+        s1[i] += r[i];
+        s2[i] = fmaf(r[i], r[i], s2[i]);
+      }
+    }
+  }
+  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.stat_sum, a.stat_sq);
+}
+
+hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st) {
+  const int slot = dtype == DT_F16 ? 8 : 4;
+  const int rpb = 256 / (a.C / slot);
+  const int npix = a.B * a.Hp * a.Wp;
+  int grid = (npix + rpb - 1) / rpb;
+  if (grid > 8192) grid = 8192;
+  const size_t smem = 2 * a.C * sizeof(float);
+  if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+// grad wrt conv0 output: dz0[y,x,c] = relu'(.) * sum over pooling windows whose saved argmax is (y,x);
+// stores s*dz0 into gy0 and reduces sum dz0, sum dz0*y0 for norm0's backward.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
+  constexpr int SLOT = TT<T>::SLOT;
+  typedef typename TT<T>::vec V;
+  extern __shared__ float red[];
+  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const int ncv = a.C / SLOT;
+  const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv, rpb = blockDim.x / ncv;
+  const int c = cv * SLOT;
+  float sc[SLOT], sh[SLOT], q[SLOT], rr[SLOT], s1[SLOT], s2[SLOT];
+  load_f32s<SLOT>(a.scale + c, sc);
+  load_f32s<SLOT>(a.shift + c, sh);
+  load_f32s<SLOT>(a.q + c, q);
+  load_f32s<SLOT>(a.r + c, rr);
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  const int npix = a.B * a.H0 * a.W0;
+  const T* y0 = (const T*)a.y0;
+  const T* gp = (const T*)a.gpool;
+  const T* xp = (const T*)a.xpool;
+  T* gy0 = (T*)a.gy0;
+  if (rl < rpb) {
+    for (int p = blockIdx.x * rpb + rl; p < npix; p += gridDim.x * rpb) {
+      int b, y, x;
+      row_to_byx(p, a.H0, a.W0, b, y, x);
+      float g[SLOT];
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) g[i] = 0.f;
+      // windows (oy, ox) with 2*oy-1 <= y <= 2*oy+1
+      const int oy0 = y >> 1, oy1 = (y + 1) >> 1;  // oy0 <= oy1, may coincide
+      const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
+      for (int wy = oy0; wy <= oy1; ++wy) {
+        if (wy >= a.Hp) continue;
+        const int ky = y - (2 * wy - 1);
+        for (int wx = ox0; wx <= ox1; ++wx) {
+          if (wx >= a.Wp) continue;
+          const int kx = x - (2 * wx - 1);
+          const int k = ky * 3 + kx;
+          const size_t op = (size_t)(b * a.Hp + wy) * a.Wp + wx;
+          float gf[SLOT], xf[SLOT];
+          vec_to_f32<T>(*(const V*)(gp + op * a.ldg + c), gf);
+          vec_to_f32<T>(*(const V*)(xp + op * a.ldg + c), xf);
+#pragma unroll
+          for (int i = 0; i < SLOT; ++i)
+            if (a.argmax[op * a.C + c + i] == k) g[i] += gf[i] + fmaf(rr[i], xf[i], q[i]);
+        }
+      }
+      float yf[SLOT], o[SLOT];
+      vec_to_f32<T>(*(const V*)(y0 + (size_t)p * a.ld0 + c), yf);
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) {
+        const float dz = (fmaf(yf[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
+        s1[i] += dz;
+        s2[i] = fmaf(dz, yf[i], s2[i]);
+        o[i] = sc[i] * dz;
+      }
+      *(V*)(gy0 + (size_t)p * a.ld0 + c) = f32_to_vec<T>(o);
+    }
+  }
+  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.red1, a.red2);
+}
+
+hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st) {
+  const int slot = dtype == DT_F16 ? 8 : 4;
+  const int rpb = 256 / (a.C / slot);
+  const int npix = a.B * a.H0 * a.W0;
+  int grid = (npix + rpb - 1) / rpb;
+  if (grid > 8192) grid = 8192;
+  const size_t smem = 2 * a.C * sizeof(float);
+  if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[] (doubles): [0..NC) loss sums, [NC..2NC) equal counts, then per image b: inter[NC], union[NC]
+template <typename T>
+__global__ __launch_bounds__(256) void bce_metrics_kernel(BceArgs a) {
+  __shared__ float red[4 * 8];
+  if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const size_t plane = (size_t)a.H * a.W;
+  float ls[8], eq[8], in_[8], un[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { ls[n] = eq[n] = in_[n] = un[n] = 0.f; }
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (size_t)gridDim.x * blockDim.x) {
+    float g[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      g[n] = 0.f;
+      if (n < a.NC) {
+        const size_t idx = ((size_t)b * a.NC + n) * plane + p;
+        const float x = a.logits[idx], t = a.target[idx];
+        const float e = expf(-fabsf(x));
+        ls[n] += fmaxf(x, 0.f) - x * t + log1pf(e);
+        const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        g[n] = (sig - t) * a.loss_scale;
+        const bool pp = x >= a.thr, gg = t >= a.thr;
+        eq[n] += (pp == gg) ? 1.f : 0.f;
+        in_[n] += (pp && gg) ? 1.f : 0.f;
+        un[n] += (pp || gg) ? 1.f : 0.f;
+      }
+    }
+    if (a.dlogits != nullptr) {
+      T* d = (T*)a.dlogits + ((size_t)b * plane + p) * 8;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) d[n] = from_f32<T>(g[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    if (n >= a.NC) break;
+    float v0 = ls[n], v1 = eq[n], v2 = in_[n], v3 = un[n];
+    for (int o = 32; o > 0; o >>= 1) {
+      v0 += __shfl_down(v0, o); v1 += __shfl_down(v1, o); v2 += __shfl_down(v2, o); v3 += __shfl_down(v3, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&red[n], v0); atomicAdd(&red[8 + n], v1); atomicAdd(&red[16 + n], v2); atomicAdd(&red[24 + n], v3);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < a.NC) {
+    const int n = threadIdx.x;
+    atomic_add_f64(a.out + n, (double)red[n]);
+    atomic_add_f64(a.out + a.NC + n, (double)red[8 + n]);
+    atomic_add_f64(a.out + 2 * a.NC + (size_t)b * 2 * a.NC + n, (double)red[16 + n]);
+    atomic_add_f64(a.out + 2 * a.NC + (size_t)b * 2 * a.NC + a.NC + n, (double)red[24 + n]);
+  }
+}
+
+hipError_t launch_bce_metrics(const BceArgs& a, int dtype, hipStream_t st) {
+  const size_t plane = (size_t)a.H * a.W;
+  // <= 4096 pixels per thread keeps the per-thread float counters exact
+  int gx = (int)((plane + 256 * 16 - 1) / (256 * 16));
+  if (gx < 1) gx = 1;
+  dim3 grid(gx, a.B);
+  if (dtype == DT_F16) hipLaunchKernelGGL(bce_metrics_kernel<f16>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bce_metrics_kernel<float>, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float g = a.g[i] * a.grad_scale;
+    float p = a.p[i];
+    if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    a.p[i] = p - a.step_size * (m / denom);
+  }
+}
+
+hipError_t launch_adam(const AdamArgs& a, hipStream_t st) {
+  int grid = (int)((a.n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack: one thread per (chunk, n) row of BK elements.  unpack: the same enumeration run backwards.
+__device__ __forceinline__ bool pack_locate(const PackDesc& d, int chunk, int kk, int BK, int& seg, int& tap, int& ch) {
+  int s = 0, lc = chunk;
+  while (s < d.nseg && lc >= d.seg[s].nchunks) { lc -= d.seg[s].nchunks; ++s; }
+  if (s >= d.nseg) return false;
+  const int e = lc * BK + kk;
+  tap = e / d.seg[s].Cpad;
+  ch = e - tap * d.seg[s].Cpad;
+  seg = s;
+  return tap < d.seg[s].ntaps && ch < d.seg[s].Creal;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, const int* row_prefix, int ndesc, int total_rows) {
+  constexpr int BK = 4 * TT<T>::SLOT;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= total_rows) return;
+  int lo = 0, hi = ndesc - 1;  // last desc with row_prefix[desc] <= row
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (row_prefix[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc& d = descs[lo];
+  const int lr = row - row_prefix[lo];
+  const int chunk = lr / d.Npad, n = lr - chunk * d.Npad;
+  T* dst = (T*)d.dst + ((size_t)chunk * d.Npad + n) * BK;
+  for (int kk = 0; kk < BK; ++kk) {
+    int s, tap, ch;
+    float v = 0.f;
+    if (n < d.N && pack_locate(d, chunk, kk, BK, s, tap, ch)) {
+      const unsigned tw = d.seg[s].tapw[tap];
+      const size_t base = (size_t)n * d.sn + (size_t)(d.seg[s].koff + ch) * d.sk;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned mt = (tw >> (8 * u)) & 0xff;
+        if (mt != 0xff) v += d.w[base + (size_t)mt * d.st];
+      }
+    }
+    dst[kk] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* descs, const int* row_prefix, int ndesc, int total_rows,
+                                                     float grad_scale) {
+  constexpr int BK = 4 * TT<T>::SLOT;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= total_rows) return;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (row_prefix[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc& d = descs[lo];
+  if (d.dpack == nullptr || d.gw == nullptr) return;
+  const int lr = row - row_prefix[lo];
+  const int chunk = lr / d.Npad, n = lr - chunk * d.Npad;
+  if (n >= d.N) return;
+  const float* src = d.dpack + ((size_t)chunk * d.Npad + n) * BK;
+  for (int kk = 0; kk < BK; ++kk) {
+    int s, tap, ch;
+    if (!pack_locate(d, chunk, kk, BK, s, tap, ch)) continue;
+    const float v = src[kk] * grad_scale;
+    const unsigned tw = d.seg[s].tapw[tap];
+    const size_t base = (size_t)n * d.sn + (size_t)(d.seg[s].koff + ch) * d.sk;
+    const bool merged = ((tw >> 8) & 0xff) != 0xff;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned mt = (tw >> (8 * u)) & 0xff;
+      if (mt == 0xff) continue;
+      if (merged || d.shared_master) atomic_add_f32(d.gw + base + (size_t)mt * d.st, v);
+      else d.gw[base + (size_t)mt * d.st] = v;
+    }
+  }
+}
+
+hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st) {
+  if (total_rows <= 0) return hipSuccess;
+  dim3 grid((total_rows + 255) / 256), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(pack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
+  else hipLaunchKernelGGL(pack_kernel<float>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
+                         hipStream_t st) {
+  if (total_rows <= 0) return hipSuccess;
+  dim3 grid((total_rows + 255) / 256), block(256);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(unpack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows, grad_scale);
+  else
+    hipLaunchKernelGGL(unpack_kernel<float>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows, grad_scale);
+  return hipGetLastError();
+}
+
+}  // namespace dmm

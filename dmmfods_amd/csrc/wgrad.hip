@@ -1,0 +1,287 @@
+// Weight-gradient GEMM for gfx950:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k]
+//   A    = exactly the gathered operand of the forward implicit GEMM (same taps, BN+ReLU prologue, modes)
+//   dYeff= output gradient with the deferred BatchNorm-backward correction  g + q[n] + r[n]*y  applied on load
+//   dP   = gradient w.r.t. the PACKED weights (fp32, layout [chunk][Npad][BK]); unpack_grads scatters it back.
+// The contraction index is the pixel m, which is the slow (strided) index of both NHWC operands, so both MFMA
+// operands are read from row-major LDS tiles with the hardware transposing read ds_read_b64_tr_b16 (16-bit
+// types) or plain ds_read_b32 (fp32).  A workgroup owns an n-tile (<=128) x 128 k-elements of dP and a range
+// of rows; partial sums are added to dP with fp32 atomics (128-byte contiguous segments per wave instruction).
+#include "common.h"
+#include "gather.h"
+
+namespace dmm {
+
+constexpr int KW = 128;  // k elements per workgroup
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<f16> { static constexpr int BMW = 128; };
+template <> struct WgCfg<float> { static constexpr int BMW = 32; };
+
+template <typename T, int WBN>
+struct WgradSmem {
+  static constexpr int BMW = WgCfg<T>::BMW;
+  // pitches chosen so that (pitch/4) mod 64 is 16 or 48: 4 consecutive rows of a transposed read tile the banks
+  static constexpr int pitch_for(int row_bytes) {
+    int p = row_bytes;
+    while (((p / 4) % 64) != 16 && ((p / 4) % 64) != 48) p += 16;
+    return p;
+  }
+  static constexpr int PD = pitch_for(WBN * (int)sizeof(T));
+  static constexpr int PA = pitch_for(KW * (int)sizeof(T));
+  static constexpr int D_BYTES = BMW * PD;
+  static constexpr int A_BYTES = BMW * PA;
+  static constexpr int TAB = 2 * BMW * 16;  // two row tables of int4 {b, y, x, outpix}
+  static constexpr int bytes = D_BYTES + A_BYTES + TAB;
+};
+
+__device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
+  typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(p));
+  return *(f16x4*)&r;
+}
+
+template <typename T, int WBN, bool MFMA>
+__global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
+  constexpr int SLOT = TT<T>::SLOT;
+  constexpr int BK = 4 * SLOT;
+  constexpr int KCH = KW / BK;  // chunks per workgroup
+  typedef typename TT<T>::vec V;
+  typedef WgradSmem<T, WBN> SM;
+  constexpr int BMW = SM::BMW;
+  constexpr int WAVES_N = WBN / 32, WAVES_K = 4 / WAVES_N;
+  constexpr int TPW = (KW / 32) / WAVES_K;  // 32x32 k-tiles per wave
+  constexpr int NCA = KW / SLOT, RGA = NTHREADS / NCA, LA = BMW / RGA;
+  constexpr int NCD = WBN / SLOT, RGD = NTHREADS / NCD, LD = (BMW + RGD - 1) / RGD;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ds = smem;
+  unsigned char* As = smem + SM::D_BYTES;
+  int4* rowtab = (int4*)(smem + SM::D_BYTES + SM::A_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = a.Npad / WBN;
+  int bid = blockIdx.x;
+  const int ntile = bid % ntiles; bid /= ntiles;
+  const int kg = bid % a.kgroups;
+  const int split = bid / a.kgroups;
+  const int n0 = ntile * WBN;
+  const int mbeg = split * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  if (mbeg >= mend) return;
+
+  // ---- this thread's fixed K position for the A tile ----
+  const int ca = tid % NCA, rga = tid / NCA;
+  int total = 0;
+  for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
+  int ks = 0, ktap = 1 << 20, kc = 0;
+  {
+    int gc = kg * KCH + (ca * SLOT) / BK;
+    if (gc < total) {
+      int s = 0;
+      while (gc >= a.seg[s].nchunks) { gc -= a.seg[s].nchunks; ++s; }
+      const int e = gc * BK + (ca * SLOT) % BK;
+      ks = s;
+      ktap = e / a.seg[s].Cpad;
+      kc = e - ktap * a.seg[s].Cpad;
+    }
+  }
+  const int cd = tid % NCD, rgd = tid / NCD;
+  const int nD = n0 + cd * SLOT;
+
+  auto fill_rowtab = [&](int which, int mt) {
+    if (tid < BMW) {
+      const int m = mt + tid;
+      int4 e;
+      if (m < mend) {
+        row_to_byx(m, a.Ho, a.Wo, e.x, e.y, e.z);
+        e.w = (e.x * a.Hout + e.y * a.ostride + a.py) * a.Wout + e.z * a.ostride + a.px;
+      } else {
+        e.x = e.y = e.z = 0;
+        e.w = -1;
+      }
+      rowtab[which * BMW + tid] = e;
+    }
+  };
+
+  V areg[LA], dreg[LD];
+  auto load_tiles = [&](int which) {
+    const Seg& sg = a.seg[ks];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int4 e = rowtab[which * BMW + rga + i * RGA];
+      areg[i] = gather_slot<T>(sg, e.x, e.y, e.z, e.w >= 0, ktap, kc);
+    }
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int row = rgd + i * RGD;
+      V v;
+#pragma unroll
+      for (int u = 0; u < SLOT; ++u) v[u] = (T)0;
+      if (row < BMW) {
+        const int4 e = rowtab[which * BMW + row];
+        if (e.w >= 0 && nD < a.N) {
+          const T* p = (const T*)a.dy.src + (size_t)e.w * a.dy.ld + nD;
+          v = *(const V*)p;
+          if (a.dy.q != nullptr) {
+            const V y2 = *(const V*)((const T*)a.dy.src2 + (size_t)e.w * a.dy.ld2 + nD);
+            float f[SLOT], f2[SLOT], q[SLOT], r[SLOT];
+            vec_to_f32<T>(v, f);
+            vec_to_f32<T>(y2, f2);
+            load_f32s<SLOT>(a.dy.q + nD, q);
+            load_f32s<SLOT>(a.dy.r + nD, r);
+#pragma unroll
+            for (int u = 0; u < SLOT; ++u) f[u] = f[u] + fmaf(r[u], f2[u], q[u]);
+            v = f32_to_vec<T>(f);
+          }
+        }
+      }
+      dreg[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = areg[i];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int row = rgd + i * RGD;
+      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = dreg[i];
+    }
+  };
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int wn = wave % WAVES_N, wk = wave / WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  // transposed-read lane geometry (16-bit types): group g = lane>>4 covers columns 16*(g&1).., rows 8*(g>>1)..
+  const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+
+  fill_rowtab(0, mbeg);
+  __syncthreads();
+  load_tiles(0);
+  int which = 0;
+  for (int mt = mbeg; mt < mend; mt += BMW) {
+    store_tiles();
+    const bool more = mt + BMW < mend;
+    if (more) fill_rowtab(which ^ 1, mt + BMW);
+    __syncthreads();
+    if (more) load_tiles(which ^ 1);
+    if (MFMA) {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ms = 0; ms < BMW / 16; ++ms) {
+          const int rowb = 16 * ms + 8 * (tg >> 1) + tq;
+          const unsigned char* dp = Ds + rowb * SM::PD + (32 * wn + 16 * (tg & 1) + 4 * tp) * 2;
+          f16x4 lo = lds_tr16(dp), hi = lds_tr16(dp + 4 * SM::PD);
+          f16x8 af;
+          af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+          af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const int kt = wk * TPW + t;
+            const unsigned char* ap = As + rowb * SM::PA + (32 * kt + 16 * (tg & 1) + 4 * tp) * 2;
+            f16x4 blo = lds_tr16(ap), bhi = lds_tr16(ap + 4 * SM::PA);
+            f16x8 bf;
+            bf[0] = blo[0]; bf[1] = blo[1]; bf[2] = blo[2]; bf[3] = blo[3];
+            bf[4] = bhi[0]; bf[5] = bhi[1]; bf[6] = bhi[2]; bf[7] = bhi[3];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int ms = 0; ms < BMW / 2; ++ms) {
+          const int row = 2 * ms + h;
+          const float av = *(const float*)(Ds + row * SM::PD + (32 * wn + r) * 4);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const int kt = wk * TPW + t;
+            const float bv = *(const float*)(As + row * SM::PA + (32 * kt + r) * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      // scalar check path, same accumulator layout: acc[t][i] <-> (n = 32*wn + rowmap(i), k = 32*kt + r)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int kt = wk * TPW + t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int nrow = 32 * wn + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float s = 0.f;
+          for (int m = 0; m < BMW; ++m)
+            s = fmaf(to_f32(*(const T*)(Ds + m * SM::PD + nrow * sizeof(T))),
+                     to_f32(*(const T*)(As + m * SM::PA + (32 * kt + r) * sizeof(T))), s);
+          acc[t][i] += s;
+        }
+      }
+    }
+    __syncthreads();
+    which ^= 1;
+  }
+
+  // ---- add the partial tile to the packed gradient ----
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int kt = wk * TPW + t;
+    const int ke = 32 * kt + r;
+    const int chunk = kg * KCH + ke / BK;
+    const int kk = ke % BK;
+    if (chunk >= total) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + 32 * wn + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (n < a.N) atomic_add_f32(a.dpack + ((size_t)chunk * a.Npad + n) * BK + kk, acc[t][i]);
+    }
+  }
+}
+
+template <typename T, int WBN>
+static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
+  typedef WgradSmem<T, WBN> SM;
+  const int ntiles = a.Npad / WBN;
+  const int splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+  dim3 grid(ntiles * a.kgroups * splits), block(NTHREADS);
+  auto kern = mfma ? wgrad_kernel<T, WBN, true> : wgrad_kernel<T, WBN, false>;
+  static bool attr_done[2] = {false, false};
+  if (SM::bytes > 48 * 1024 && !attr_done[mfma]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
+    if (e != hipSuccess) return e;
+    attr_done[mfma] = true;
+  }
+  hipLaunchKernelGGL(kern, grid, block, SM::bytes, st, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_wt(const WgradArgs& a, bool mfma, hipStream_t st) {
+  if (a.Npad % 128 == 0) return launch_w<T, 128>(a, mfma, st);
+  if (a.Npad % 64 == 0) return launch_w<T, 64>(a, mfma, st);
+  return launch_w<T, 32>(a, mfma, st);
+}
+
+// Fills rows_per_split / kgroups (if zero) and launches.
+hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
+  if (a.M <= 0) return hipSuccess;
+  const int BK = dtype == DT_F16 ? 32 : 16;
+  const int bmw = dtype == DT_F16 ? 128 : 32;
+  int total = 0;
+  for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
+  a.kgroups = (total * BK + KW - 1) / KW;
+  if (a.rows_per_split <= 0) {
+    const int wbn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
+    const int base = a.kgroups * (a.Npad / wbn);
+    // aim for ~1024 workgroups, at least 4 row steps each, at most M/steps
+    int want = (1024 + base - 1) / base;
+    int steps = (a.M + bmw - 1) / bmw;
+    int per = (steps + want - 1) / want;
+    if (per < 4) per = 4;
+    a.rows_per_split = per * bmw;
+  }
+  return dtype == DT_F16 ? launch_wt<f16>(a, mfma, st) : launch_wt<float>(a, mfma, st);
+}
+
+}  // namespace dmm

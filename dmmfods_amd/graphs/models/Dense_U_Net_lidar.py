@@ -1,0 +1,355 @@
+"""Dense_U_Net_lidar on MI355X: same constructor, forward signature, attributes and state_dict layout as the
+reference module (dmmfods/graphs/models/Dense_U_Net_lidar.py:18-388); all arithmetic runs in the HIP library
+behind include/dmmfods_hip.h.  There is no CPU path: calling forward on CPU tensors raises.
+
+Differences that are deliberate and documented:
+  * parameters are views into one flat fp32 arena (and .grad into a flat gradient arena), so Adam and the
+    data-parallel all-reduce each touch one contiguous buffer;
+  * backward overwrites .grad instead of accumulating (the reference always zero_grad()s first, A:263);
+  * ``pretrained=True`` needs torchvision's ImageNet checkpoint, which cannot be fetched offline.
+"""
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ...utils.Dense_U_Net_lidar_helper import get_config
+
+_DTYPES = {"fp32": _lib.DMM_F32, "float32": _lib.DMM_F32, "fp16": _lib.DMM_F16, "float16": _lib.DMM_F16}
+
+
+class _Node(nn.Module):
+    """Bare container; gives state_dict() the reference's dotted key layout."""
+
+
+def _make_desc(model, batch, height, width):
+    d = _lib.ModelDesc()
+    d.growth_rate = int(model.growth_rate)
+    bc = tuple(int(v) for v in model.block_config)
+    if not 2 <= len(bc) <= 8:
+        raise ValueError("block_config must have 2..8 entries")
+    d.num_blocks = len(bc)
+    for i, v in enumerate(bc):
+        d.block_config[i] = v
+    d.num_init_features = int(model.num_init_features)
+    d.bn_size = int(model.bn_size)
+    d.num_classes = int(model.num_classes)
+    d.concat_before_block_num = int(model.concat_before_block_num)
+    d.stream_1_in_channels = int(model.stream_1_in_channels)
+    d.stream_2_in_channels = int(model.stream_2_in_channels)
+    d.batch, d.height, d.width = int(batch), int(height), int(width)
+    d.dtype = _DTYPES[model.compute_dtype]
+    d.loss_scale = float(model.loss_scale)
+    d.bn_momentum, d.bn_eps = 0.1, 1e-5
+    d.iou_threshold = float(model.iou_threshold)
+    d.use_mfma = 1 if model.use_mfma else 0
+    return d
+
+
+def _tensor_table(handle):
+    L = _lib.lib()
+    out = []
+    for i in range(L.dmm_plan_num_tensors(handle)):
+        name, kind, nd = C.c_char_p(), C.c_int32(), C.c_int32()
+        shape, off = (C.c_int64 * 4)(), C.c_int64()
+        _lib.check(L.dmm_plan_tensor_info(handle, i, C.byref(name), C.byref(kind), C.byref(nd), C.byref(shape), C.byref(off)))
+        out.append((name.value.decode(), kind.value, tuple(shape[j] for j in range(nd.value)), off.value))
+    return out
+
+
+class _Plan:
+    def __init__(self, model, batch, height, width):
+        L = _lib.lib()
+        self.key = (batch, height, width)
+        self.handle = C.c_void_p()
+        desc = _make_desc(model, batch, height, width)
+        _lib.check(L.dmm_plan_create(C.byref(desc), C.byref(self.handle)))
+        nbytes = L.dmm_plan_workspace_bytes(self.handle)
+        dev = model._param_arena.device
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nc = int(model.num_classes)
+        self.metrics = torch.zeros(2 * nc + batch * 2 * nc, dtype=torch.float64, device=dev)
+        self.flops_forward = L.dmm_plan_forward_flops(self.handle)
+        _lib.check(L.dmm_plan_bind(self.handle, self.workspace.data_ptr(), nbytes, model._param_arena.data_ptr(),
+                                   model._grad_arena.data_ptr(), model._buffer_arena.data_ptr()))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().dmm_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _HipBackward(torch.autograd.Function):
+    """Ties the HIP backward pass to torch autograd: d(loss)/d(logits) comes in, parameter gradients land in the
+    model's gradient arena (p.grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, hook, logits, model, plan):
+        ctx.model, ctx.plan = model, plan
+        return logits.view_as(logits)
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        model, plan = ctx.model, ctx.plan
+        g = grad_logits.contiguous().float()
+        _lib.check(_lib.lib().dmm_plan_backward(plan.handle, g.data_ptr(), _lib.stream_ptr()))
+        model._attach_grads()
+        return torch.zeros_like(model._hook), None, None, None
+
+
+class Dense_U_Net_lidar(nn.Module):
+    """U-Net-like detector head on a DenseNet encoder with an optional LiDAR stream (reference M:18-267)."""
+
+    def __init__(self, config, compute_dtype=None, loss_scale=None, use_mfma=True):
+        super().__init__()
+        self.config = config
+        m = config.model
+        self.growth_rate = m.growth_rate
+        self.block_config = tuple(m.block_config)
+        self.num_init_features = m.num_init_features
+        self.bn_size = m.bn_size
+        self.drop_rate = m.drop_rate
+        self.memory_efficient = m.memory_efficient
+        self.num_classes = m.num_classes
+        self.concat_before_block_num = m.concat_before_block_num
+        self.num_layers_before_blocks = m.num_layers_before_blocks
+        self.concat_after_module_idx = self.num_layers_before_blocks - 1 + 2 * (self.concat_before_block_num - 1)
+        self.stream_1_in_channels = m.stream_1_in_channels
+        self.stream_2_in_channels = m.stream_2_in_channels
+        self.network_input_channels = self.stream_1_in_channels
+        if self.concat_before_block_num == 1 and self.stream_2_in_channels == 0:
+            self.fusion = "no"
+        elif self.concat_before_block_num == 1 and self.stream_2_in_channels > 0:
+            self.fusion = "early"
+            self.network_input_channels += self.stream_2_in_channels
+        elif 1 < self.concat_before_block_num <= len(self.block_config):
+            self.fusion = "mid"
+        else:
+            raise AttributeError("invalid fusion configuration")
+        if self.drop_rate:
+            raise ValueError("drop_rate > 0 is not supported by the HIP path (reference default 0, H:120)")
+        self.compute_dtype = compute_dtype or os.environ.get("DMMFODS_DTYPE", "fp32")
+        if self.compute_dtype not in _DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
+        self.loss_scale = 1.0 if loss_scale is None else float(loss_scale)
+        self.use_mfma = bool(use_mfma)
+        try:
+            self.iou_threshold = float(config.agent.iou_threshold)
+        except (AttributeError, KeyError):
+            self.iou_threshold = 0.7
+
+        # ---- state_dict layout from the library's own layer table (shape-independent) ----
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.dmm_plan_create(C.byref(_make_desc(self, 1, 32, 32)), C.byref(h)))
+        try:
+            table = _tensor_table(h)
+            nparams, nbuf = L.dmm_plan_num_params(h), L.dmm_plan_num_buffer_elems(h)
+        finally:
+            L.dmm_plan_destroy(h)
+        self._table = table
+        self._param_arena = torch.zeros(nparams, dtype=torch.float32)
+        self._grad_arena = torch.zeros(nparams, dtype=torch.float32)
+        self._buffer_arena = torch.zeros(max(nbuf, 1), dtype=torch.float32)
+        n_bn = sum(1 for _, k, _, _ in table if k == _lib.T_BN_TRACKED)
+        self._tracked_arena = torch.zeros(n_bn, dtype=torch.int64)
+        self._hook = torch.zeros(1, requires_grad=True)
+        self._slots = []  # (owner module, leaf name, kind, shape, offset)
+        ti = 0
+        for name, kind, shape, off in table:
+            owner = self
+            parts = name.split(".")
+            for part in parts[:-1]:
+                if part not in owner._modules:
+                    owner.add_module(part, _Node())
+                owner = owner._modules[part]
+            leaf = parts[-1]
+            n = int(math.prod(shape)) if shape else 1
+            if kind <= _lib.T_BN_BIAS:
+                owner.register_parameter(leaf, nn.Parameter(self._param_arena[off:off + n].view(shape)))
+            elif kind <= _lib.T_BN_VAR:
+                owner.register_buffer(leaf, self._buffer_arena[off:off + n].view(shape))
+            else:
+                owner.register_buffer(leaf, self._tracked_arena[ti])
+                off = ti
+                ti += 1
+            self._slots.append((owner, leaf, kind, shape, off))
+        self._init_weights()
+        self.num_params = sum(p.numel() for p in self.parameters())
+        self._plans = OrderedDict()
+        self._last = None
+
+    # ------------------------------------------------------------------ parameters
+    def _init_weights(self):
+        """kaiming_normal_ on Conv2d, PyTorch's default (kaiming_uniform a=sqrt(5)) on ConvTranspose2d, BN 1/0
+        (reference M:198-205; ConvTranspose2d is not an nn.Conv2d subclass so it keeps its default)."""
+        with torch.no_grad():
+            for owner, leaf, kind, shape, off in self._slots:
+                t = getattr(owner, leaf)
+                if kind == _lib.T_CONV:
+                    nn.init.kaiming_normal_(t)
+                elif kind == _lib.T_CONVT:
+                    nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+                elif kind == _lib.T_BN_WEIGHT or kind == _lib.T_BN_VAR:
+                    t.fill_(1.0)
+                elif kind == _lib.T_BN_BIAS or kind == _lib.T_BN_MEAN:
+                    t.zero_()
+
+    def _apply(self, fn, recurse=True):
+        """Move the arenas, then re-point every parameter / buffer at its slice (keeps them views)."""
+        def move(t, dtype):
+            r = fn(t)
+            return r.to(dtype) if r.dtype != dtype else r
+        self._param_arena = move(self._param_arena, torch.float32)
+        self._grad_arena = move(self._grad_arena, torch.float32)
+        self._buffer_arena = move(self._buffer_arena, torch.float32)
+        self._tracked_arena = move(self._tracked_arena, torch.int64)
+        self._hook = torch.zeros(1, requires_grad=True, device=self._param_arena.device)
+        for owner, leaf, kind, shape, off in self._slots:
+            n = int(math.prod(shape)) if shape else 1
+            if kind <= _lib.T_BN_BIAS:
+                p = owner._parameters[leaf]
+                p.data = self._param_arena[off:off + n].view(shape)
+                p.grad = None
+            elif kind <= _lib.T_BN_VAR:
+                owner._buffers[leaf] = self._buffer_arena[off:off + n].view(shape)
+            else:
+                owner._buffers[leaf] = self._tracked_arena[off]
+        self._plans = OrderedDict()
+        self._last = None
+        return self
+
+    def _attach_grads(self):
+        for owner, leaf, kind, shape, off in self._slots:
+            if kind <= _lib.T_BN_BIAS:
+                p = owner._parameters[leaf]
+                if p.grad is None or p.grad.data_ptr() != self._grad_arena.data_ptr() + 4 * off:
+                    p.grad = self._grad_arena[off:off + p.numel()].view(shape)
+
+    @property
+    def param_arena(self):
+        return self._param_arena
+
+    @property
+    def grad_arena(self):
+        return self._grad_arena
+
+    # ------------------------------------------------------------------ plans
+    def _get_plan(self, batch, height, width):
+        key = (batch, height, width)
+        plan = self._plans.get(key)
+        if plan is None:
+            while len(self._plans) >= 2:  # each plan owns a multi-GB workspace
+                self._plans.popitem(last=False)
+            plan = _Plan(self, batch, height, width)
+            self._plans[key] = plan
+        else:
+            self._plans.move_to_end(key)
+        return plan
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, stream_1_data, stream_2_data):
+        """stream_1_data (B, s1, H, W), stream_2_data (B, s2, H, W) float NCHW -> logits (B, num_classes, H, W)."""
+        x1 = stream_1_data
+        if not x1.is_cuda:
+            raise RuntimeError("dmmfods_amd computes on the GPU only; move the model and inputs to 'cuda' (no CPU fallback)")
+        if x1.device != self._param_arena.device:
+            raise RuntimeError("model and inputs are on different devices")
+        B, c1, H, W = x1.shape
+        if c1 != self.stream_1_in_channels:
+            raise RuntimeError(f"stream_1 has {c1} channels, expected {self.stream_1_in_channels}")
+        x1 = x1.contiguous().float()
+        x2 = None
+        if self.fusion != "no":
+            x2 = stream_2_data
+            if self.fusion == "mid":
+                assert tuple(x2.shape[2:]) == (H, W) and x2.shape[0] == B, f"{tuple(x1.shape)} {tuple(x2.shape)}"
+            elif tuple(x2.shape[2:]) != (H, W) or x2.shape[0] != B:
+                raise RuntimeError("Sizes of tensors must match except in dimension 1")
+            if x2.shape[1] != self.stream_2_in_channels:
+                raise RuntimeError(f"stream_2 has {x2.shape[1]} channels, expected {self.stream_2_in_channels}")
+            x2 = x2.contiguous().float()
+        plan = self._get_plan(B, H, W)
+        logits = torch.empty(B, self.num_classes, H, W, dtype=torch.float32, device=x1.device)
+        _lib.check(_lib.lib().dmm_plan_forward(plan.handle, x1.data_ptr(), x2.data_ptr() if x2 is not None else None,
+                                               logits.data_ptr(), 1 if self.training else 0, _lib.stream_ptr()))
+        if self.training:
+            self._tracked_arena += 1
+        self._last = (plan, logits)
+        if self.training and torch.is_grad_enabled():
+            return _HipBackward.apply(self._hook, logits, self, plan)
+        return logits
+
+    def loss_backward(self, target):
+        """Fused training tail (reference A:247-264): per-pixel BCE-with-logits on the last forward's logits, metric
+        counts, and backward of the SUM of all loss elements.  Returns a dict of device tensors."""
+        if self._last is None:
+            raise RuntimeError("loss_backward() needs a preceding training-mode forward()")
+        plan, logits = self._last
+        t = target.contiguous().float()
+        _lib.check(_lib.lib().dmm_plan_loss_backward(plan.handle, logits.data_ptr(), t.data_ptr(), plan.metrics.data_ptr(),
+                                                     _lib.stream_ptr()))
+        self._attach_grads()
+        return self._metrics(plan, logits.shape)
+
+    def loss_metrics(self, logits, target):
+        """Loss sums and metric counts only (validation, A:345-358)."""
+        plan = self._get_plan(logits.shape[0], logits.shape[2], logits.shape[3])
+        t = target.contiguous().float()
+        lg = logits.detach().contiguous().float()
+        _lib.check(_lib.lib().dmm_plan_loss_metrics(plan.handle, lg.data_ptr(), t.data_ptr(), plan.metrics.data_ptr(),
+                                                    _lib.stream_ptr()))
+        return self._metrics(plan, logits.shape)
+
+    def _metrics(self, plan, shape):
+        B, nc, H, W = shape
+        m = plan.metrics.clone()
+        per = m[2 * nc:].view(B, 2, nc)
+        inter, union = per[:, 0], per[:, 1]
+        return {
+            "loss_per_class": m[:nc].float(),
+            "acc_per_class": (m[nc:2 * nc] / float(B * H * W)).float(),
+            "iou_per_instance_per_class": (inter / union).float(),  # 0/0 -> NaN, as in the reference (H:337-341)
+            "intersection": inter, "union": union,
+        }
+
+
+def _load_state_dict(model, config, model_url, progress):
+    raise RuntimeError("pretrained torchvision weights cannot be downloaded in this environment; load a checkpoint with "
+                       "model.load_state_dict(...) instead (state_dict keys match the reference)")
+
+
+def _dense_u_net_lidar(arch, growth_rate, block_config, num_init_features, pretrained, progress, config, **kw):
+    if config is None:
+        config = get_config(os.path.join("content", "mnt", "My Drive", "Colab Notebooks", "DeepCV_Packages"))
+    # for compatibility with the original densenet functions the factory overwrites these (reference M:323-325)
+    config.model.growth_rate = growth_rate
+    config.model.block_config = block_config
+    config.model.num_init_features = num_init_features
+    model = Dense_U_Net_lidar(config, **kw)
+    if pretrained:
+        _load_state_dict(model, config, arch, progress)
+    return model
+
+
+def densenet121_u_lidar(pretrained=False, progress=True, config=None, **kw):
+    return _dense_u_net_lidar("densenet121", 32, (6, 12, 24, 16), 64, pretrained, progress, config, **kw)
+
+
+def densenet161_u_lidar(pretrained=False, progress=True, config=None, **kw):
+    return _dense_u_net_lidar("densenet161", 48, (6, 12, 36, 24), 96, pretrained, progress, config, **kw)
+
+
+def densenet169_u_lidar(pretrained=False, progress=True, config=None, **kw):
+    return _dense_u_net_lidar("densenet169", 32, (6, 12, 32, 32), 64, pretrained, progress, config, **kw)
+
+
+def densenet201_u_lidar(pretrained=False, progress=True, config=None, **kw):
+    return _dense_u_net_lidar("densenet201", 32, (6, 12, 48, 32), 64, pretrained, progress, config, **kw)

@@ -1,0 +1,138 @@
+/* dmmfods_hip.h -- C ABI of libdmmfods_hip.so: the MI355X (gfx950) implementation of the DMMFODS
+ * Dense_U_Net_lidar training hot path.
+ *
+ * The reference (p-mc-grath/DMMFODS) is pure Python on torch.nn and has NO FFI of its own; its drop-in
+ * boundary is the Python surface of  dmmfods/graphs/models/Dense_U_Net_lidar.py  and
+ * dmmfods/agents/Dense_U_Net_lidar_Agent.py.  Each entry point below names the reference interface it
+ * stands behind (paths relative to the reference tree):
+ *
+ *   dmm_plan_create / dmm_plan_destroy ... Dense_U_Net_lidar.__init__   graphs/models/Dense_U_Net_lidar.py:29-208
+ *   dmm_plan_tensor_*  .................... nn.Module.state_dict() key/shape layout   (same file, :71-192)
+ *   dmm_plan_forward ..................... Dense_U_Net_lidar.forward    graphs/models/Dense_U_Net_lidar.py:210-267
+ *   dmm_plan_loss_backward ............... BCEWithLogitsLoss(reduction='none') + metrics + backward(ones)
+ *                                          agents/Dense_U_Net_lidar_Agent.py:247-264, utils/...helper.py:311-401
+ *   dmm_adam_step ........................ torch.optim.Adam.step        agents/Dense_U_Net_lidar_Agent.py:57-61,265
+ *   dmm_conv_forward / dmm_conv_wgrad .... single-kernel entry points for unit tests (torch.nn.functional.conv2d,
+ *                                          conv_transpose2d as dispatched by the modules built at :72-131)
+ *
+ * Conventions: every function returns 0 on success and a negative dmm_status otherwise; dmm_last_error()
+ * gives the message (thread-local).  The caller owns all buffers (device pointers are plain void*); the
+ * library owns only the opaque plan.  A plan is bound to one device and is not thread-safe.  All launches go
+ * to the hipStream_t passed as `stream` (a void* here so that the header needs no HIP include).
+ */
+#ifndef DMMFODS_HIP_H
+#define DMMFODS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DMM_OK = 0,
+  DMM_ERR_INVALID = -1,      /* bad argument / unsupported configuration (Python raises AttributeError/ValueError) */
+  DMM_ERR_SHAPE = -2,        /* spatial size not a multiple of 32 (reference: ValueError from ConvTranspose2d) */
+  DMM_ERR_HIP = -3,          /* a HIP call failed */
+  DMM_ERR_STATE = -4,        /* plan not bound / wrong call order */
+  DMM_ERR_NO_DEVICE = -5
+} dmm_status;
+
+enum { DMM_F32 = 0, DMM_F16 = 1 };
+
+/* tensor kinds in the state_dict table */
+enum { DMM_T_CONV = 0, DMM_T_CONVT = 1, DMM_T_BN_WEIGHT = 2, DMM_T_BN_BIAS = 3, DMM_T_BN_MEAN = 4, DMM_T_BN_VAR = 5,
+       DMM_T_BN_TRACKED = 6 };
+
+/* Mirrors config.model.* of the reference (utils/Dense_U_Net_lidar_helper.py:110-123) plus the run shape. */
+typedef struct {
+  int32_t growth_rate;
+  int32_t num_blocks;
+  int32_t block_config[8];
+  int32_t num_init_features;
+  int32_t bn_size;
+  int32_t num_classes;
+  int32_t concat_before_block_num;
+  int32_t stream_1_in_channels;
+  int32_t stream_2_in_channels;
+  int32_t batch, height, width; /* per-GPU minibatch and input size (H, W multiples of 32) */
+  int32_t dtype;                /* DMM_F32 (parity) or DMM_F16 (storage/MFMA type; fp32 accumulate) */
+  float loss_scale;             /* multiplies d(loss)/d(logit); gradients are un-scaled before they are returned */
+  float bn_momentum, bn_eps;    /* 0.1, 1e-5 */
+  float iou_threshold;          /* config.agent.iou_threshold, 0.7, applied to raw logits (reference quirk) */
+  int32_t use_mfma;             /* 1 = MFMA kernels; 0 = scalar check kernels (bring-up / debugging) */
+} dmm_model_desc;
+
+typedef struct dmm_plan dmm_plan;
+
+const char* dmm_last_error(void);
+int dmm_version(void);
+
+/* Plan construction needs no GPU: it derives the layer table, the state_dict layout and the workspace size. */
+int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out);
+void dmm_plan_destroy(dmm_plan* plan);
+
+/* state_dict layout, in the reference's registration order */
+int dmm_plan_num_tensors(const dmm_plan* plan);
+/* shape has 4 entries (unused = 0), *arena_offset is in elements of the param arena (trainable tensors) or of the
+ * buffer arena (running_mean / running_var); num_batches_tracked has no arena slot (offset -1). */
+int dmm_plan_tensor_info(const dmm_plan* plan, int index, const char** name, int32_t* kind, int32_t* ndim,
+                         int64_t shape[4], int64_t* arena_offset);
+int64_t dmm_plan_num_params(const dmm_plan* plan);        /* elements of the param / grad arena */
+int64_t dmm_plan_num_buffer_elems(const dmm_plan* plan);  /* elements of the running-stat arena */
+size_t dmm_plan_workspace_bytes(const dmm_plan* plan);
+double dmm_plan_forward_flops(const dmm_plan* plan);      /* 2*MACs of all convolutions, whole batch */
+
+/* Bind device memory: workspace (>= workspace_bytes, 256-byte aligned), fp32 param arena, fp32 grad arena,
+ * fp32 running-stat arena.  May be called again after a re-allocation. */
+int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float* params, float* grads, float* buffers);
+
+/* stream_1 (B,s1,H,W) and stream_2 (B,s2,H,W; may be NULL when s2 == 0) are fp32 NCHW device tensors;
+ * logits_out is (B,num_classes,H,W) fp32 NCHW.  training != 0: batch statistics + running-stat update. */
+int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_2, float* logits_out, int training,
+                     void* stream);
+
+/* After a training-mode forward: per-pixel BCE against target (B,num_classes,H,W fp32), metric counts, and the
+ * backward pass of the SUM of all loss elements.  Gradients land in the bound grad arena (fully overwritten).
+ * metrics_out (device, doubles): [NC loss sums | NC equal-counts | B x (NC intersections, NC unions)]. */
+int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream);
+
+/* Backward from an externally computed d(loss)/d(logit) (B,num_classes,H,W fp32), e.g. from torch autograd of any
+ * loss on the returned logits (reference: loss.backward(...), agents/Dense_U_Net_lidar_Agent.py:264). */
+int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream);
+
+/* Loss + metrics only (validation). */
+int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream);
+
+/* Flat fused Adam over n fp32 elements (amsgrad unsupported).  step is 1-based. */
+int dmm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ---- single-kernel entry points (unit tests) ---- */
+typedef struct {
+  int32_t dtype, use_mfma;
+  int32_t B, H, W;         /* input spatial size */
+  int32_t Cin, Cout;       /* real channels; Cin is a multiple of 8 */
+  int32_t R, S, stride, pad;
+  int32_t transposed;      /* 1: ConvTranspose2d(k=3, s=2, p=1, output_padding=1), weight (Cin, Cout, 3, 3) */
+  int32_t mode;            /* 0 plain, 1 nearest-upsample x2 source, 2 avg-pool 2x2 then 1x1 */
+  int32_t bn_relu;         /* apply relu(x*scale+shift) to the input first */
+} dmm_conv_desc;
+
+/* x: T NHWC (B,H,W,Cin); w: fp32 master weights; y: T NHWC output; stats: 2*Cout doubles (sum, sumsq; zeroed by the
+ * callee) or NULL; scratch: >= dmm_conv_scratch_bytes. */
+size_t dmm_conv_scratch_bytes(const dmm_conv_desc* d);
+int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, const float* scale, const float* shift, void* y,
+                     double* stats, void* scratch, void* stream);
+/* dw: fp32, master layout, overwritten.  dy: T NHWC gradient of the conv output. */
+int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, float* dw,
+                   void* scratch, void* stream);
+/* BN+ReLU-fused data gradient: gx (T, NHWC like x) = scale * relu'(x*scale+shift) * conv_dgrad(dy); red: 2*Cin doubles
+ * (sum dz, sum dz*x; zeroed by the callee). */
+int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
+                   void* gx, double* red, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMMFODS_HIP_H */

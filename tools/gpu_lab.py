@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Bring-up lab: runs every kernel family against a torch reference and the tiny model against the oracle,
+printing errors for ALL cases (never stops at the first failure).  Usage on the GPU box:
+    python tools/gpu_lab.py [kernels] [model] > gpurun_out/lab.log
+"""
+import ctypes as C
+import os
+import sys
+import time
+import traceback
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dmmfods_amd import _lib  # noqa: E402
+
+DEV = "cuda"
+L = _lib.lib()
+
+
+def nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt)
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous().float()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transposed=0, mode=0, bn=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.float16 if dtype == 1 else torch.float32
+    x = (torch.randn(B, Cin, H, W, generator=g) * 2 + 0.5)
+    scale = torch.rand(Cin, generator=g) + 0.5
+    shift = torch.randn(Cin, generator=g) * 0.5
+    wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, R, S)
+    w = torch.randn(wshape, generator=g) / (Cin * R * S) ** 0.5
+    xq = x.to(dt).float()
+    a = F.relu(xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) if bn else xq
+    a = a.requires_grad_(True)
+    wq = w.clone().requires_grad_(True)
+    if transposed:
+        y = F.conv_transpose2d(a, wq, stride=2, padding=1, output_padding=1)
+    elif mode == 1:
+        y = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), wq, padding=pad)
+    elif mode == 2:
+        y = F.avg_pool2d(F.conv2d(a, wq), 2, 2)
+    else:
+        y = F.conv2d(a, wq, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    dyq = dy.to(dt).float()
+    (y * dyq).sum().backward()
+    d = _lib.ConvDesc(dtype=dtype, use_mfma=mfma, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, stride=stride, pad=pad,
+                      transposed=transposed, mode=mode, bn_relu=bn)
+    nsc = L.dmm_conv_scratch_bytes(C.byref(d))
+    scratch = torch.zeros(nsc, dtype=torch.uint8, device=DEV)
+    xd = nhwc(x, dt).to(DEV)
+    wd, sd, hd = w.to(DEV), scale.to(DEV), shift.to(DEV)
+    yd = torch.full((B, y.shape[2], y.shape[3], Cout), float("nan"), dtype=dt, device=DEV)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    st = _lib.stream_ptr()
+    res = {}
+    _lib.check(L.dmm_conv_forward(C.byref(d), xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(), yd.data_ptr(),
+                                  stats.data_ptr(), scratch.data_ptr(), st))
+    torch.cuda.synchronize()
+    yo = nchw(yd).cpu()
+    res["fwd"] = relerr(yo, y.detach())
+    res["sum"] = relerr(stats[:Cout].cpu(), yo.double().sum(dim=(0, 2, 3)))
+    res["sq"] = relerr(stats[Cout:].cpu(), (yo.double() ** 2).sum(dim=(0, 2, 3)))
+    # wgrad
+    dyd = nhwc(dy, dt).to(DEV)
+    dwd = torch.full(wshape, float("nan"), device=DEV)
+    _lib.check(L.dmm_conv_wgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), sd.data_ptr(), hd.data_ptr(), dwd.data_ptr(),
+                                scratch.data_ptr(), st))
+    torch.cuda.synchronize()
+    res["wgrad"] = relerr(dwd.cpu(), wq.grad)
+    # dgrad (BN fused)
+    if bn and not (mode == 0 and not transposed and stride != 1):
+        z = xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        dz = a.grad * (z > 0)
+        gx_ref = dz * scale.view(1, -1, 1, 1)
+        gxd = torch.full((B, H, W, Cin), float("nan"), dtype=dt, device=DEV)
+        red = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+        _lib.check(L.dmm_conv_dgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(),
+                                    gxd.data_ptr(), red.data_ptr(), scratch.data_ptr(), st))
+        torch.cuda.synchronize()
+        res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref)
+        res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)))
+        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xq.double()).sum(dim=(0, 2, 3)))
+    tol = 3e-3 if dtype == 1 else 2e-5
+    bad = [k for k, v in res.items() if not (v < tol)]
+    print(f"{'FAIL' if bad else 'ok  '} {name:28s} dt={dtype} mfma={mfma} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
+    return not bad
+
+
+CASES = [
+    # name, B,H,W,Cin,Cout,R,S,stride,pad, transposed, mode, bn
+    ("1x1 72->32", 2, 12, 20, 72, 32, 1, 1, 1, 0, 0, 0, 1),
+    ("1x1 256->128", 1, 16, 24, 256, 128, 1, 1, 1, 0, 0, 0, 1),
+    ("1x1 64->256", 1, 8, 8, 64, 256, 1, 1, 1, 0, 0, 0, 1),
+    ("3x3 128->32", 2, 12, 20, 128, 32, 3, 3, 1, 1, 0, 0, 1),
+    ("3x3 32->8", 1, 9, 7, 32, 8, 3, 3, 1, 1, 0, 0, 1),
+    ("5x5 64->8", 1, 10, 14, 64, 8, 5, 5, 1, 2, 0, 0, 1),
+    ("7x7s2 8->64", 2, 32, 32, 8, 64, 7, 7, 2, 3, 0, 0, 0),
+    ("convT 64->64", 2, 6, 10, 64, 64, 3, 3, 2, 1, 1, 0, 1),
+    ("convT 16->16", 1, 5, 3, 16, 16, 3, 3, 2, 1, 1, 0, 1),
+    ("pool2 1x1 128->64", 2, 12, 20, 128, 64, 1, 1, 1, 0, 0, 2, 1),
+    ("up2 3x3 128->64", 1, 6, 10, 128, 64, 3, 3, 1, 1, 0, 1, 1),
+    ("up2 3x3 16->8", 2, 4, 4, 16, 8, 3, 3, 1, 1, 0, 1, 1),
+]
+
+
+def run_kernels():
+    ok = True
+    for dtype in (0, 1):
+        for mfma in (0, 1):
+            for c in CASES:
+                try:
+                    ok &= conv_case(c[0], dtype, mfma, *c[1:])
+                except Exception:
+                    ok = False
+                    print(f"EXC  {c[0]} dt={dtype} mfma={mfma}\n" + traceback.format_exc(), flush=True)
+    return ok
+
+
+def run_model(variants=("no", "early", "mid3", "mid2", "mid4"), dtypes=("fp32", "fp16"), mfma=True):
+    from oracle import restatement as R
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    V = {"no": (1, 0), "early": (1, 3), "mid2": (2, 3), "mid3": (3, 3), "mid4": (4, 3)}
+    ok = True
+    for v in variants:
+        cbb, s2 = V[v]
+        arch = R.Arch(growth_rate=8, block_config=(2, 2, 2, 2), num_init_features=16, concat_before_block_num=cbb,
+                      stream_2_in_channels=s2)
+        # oracle in fp64 (truth) and fp32 (noise floor)
+        outs = {}
+        for odt in (torch.float64, torch.float32):
+            P = {k: (t.to(odt) if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=123).items()}
+            tr = R.Trainer(arch, P)
+            rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=0)
+            o = tr.step(rgb.to(odt), lidar.to(odt), tgt.to(odt), do_update=False)
+            outs[odt] = (o, {k: t.grad.clone() for k, t in tr.leaves}, P)
+        o64, g64, P64 = outs[torch.float64]
+        o32, g32, _ = outs[torch.float32]
+        for dts in dtypes:
+            try:
+                cfg = get_config("/tmp/dmm")
+                cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = 8, (2, 2, 2, 2), 16
+                cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = cbb, s2
+                model = Dense_U_Net_lidar(cfg, compute_dtype=dts, use_mfma=mfma)
+                model.load_state_dict(R.make_state(arch, seed=123))
+                model = model.to(DEV).train()
+                rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=0)
+                logits = model(rgb.to(DEV), lidar.to(DEV))
+                met = model.loss_backward(tgt.to(DEV))
+                torch.cuda.synchronize()
+                e_log = relerr(logits.detach().cpu(), o64["logits"])
+                n_log = relerr(o32["logits"], o64["logits"])
+                e_loss = relerr(met["loss_per_class"].cpu(), o64["loss_per_class"])
+                iou_ok = torch.allclose(met["iou_per_instance_per_class"].cpu(), o64["iou"].float(), atol=2e-2, equal_nan=True)
+                worst = []
+                for k, p in model.named_parameters():
+                    ref = g64[k]
+                    s = ref.abs().max().clamp_min(1e-30)
+                    e = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
+                    n = ((g32[k].double() - ref).abs().max() / s).item()
+                    worst.append((e, n, k))
+                worst.sort(reverse=True)
+                sd = model.state_dict()
+                e_rm = max(relerr(sd[k].cpu(), P64[k]) for k in sd if k.endswith("running_mean"))
+                e_rv = max(relerr(sd[k].cpu(), P64[k]) for k in sd if k.endswith("running_var"))
+                tol = 1e-3 if dts == "fp32" else 5e-2
+                bad = e_log > tol or worst[0][0] > (3e-3 if dts == "fp32" else 0.2) or not iou_ok
+                ok &= not bad
+                print(f"{'FAIL' if bad else 'ok  '} model {v:6s} {dts} mfma={int(mfma)} logits={e_log:.2e} (cpu32 {n_log:.1e}) loss={e_loss:.2e} "
+                      f"iou_ok={iou_ok} rm={e_rm:.1e} rv={e_rv:.1e}", flush=True)
+                for e, n, k in worst[:6]:
+                    print(f"        grad err {e:.2e} (cpu32 {n:.1e}) {k}", flush=True)
+            except Exception:
+                ok = False
+                print(f"EXC  model {v} {dts}\n" + traceback.format_exc(), flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["kernels", "model"]
+    print(torch.cuda.get_device_name(0), flush=True)
+    t0 = time.time()
+    ok = True
+    if "kernels" in what:
+        ok &= run_kernels()
+    if "model" in what:
+        ok &= run_model()
+    if "model_scalar" in what:
+        ok &= run_model(variants=("no",), dtypes=("fp32",), mfma=False)
+    print(f"LAB {'PASS' if ok else 'FAIL'} in {time.time() - t0:.1f}s", flush=True)
