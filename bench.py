@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Training-throughput benchmark of the Dense_U_Net_lidar hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + per-pixel BCE + metrics + backward + (DP: gradient all-reduce) + Adam on one synthetic
+minibatch that is already resident in HBM.  Rank 0 prints ONE JSON line (Measurement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DENSENETS = {121: (32, (6, 12, 24, 16), 64), 169: (32, (6, 12, 32, 32), 64), 201: (32, (6, 12, 48, 32), 64)}
+# BASELINE.json configs.  C2 (configs[1]) is the 1-GPU configuration the metric is quoted on.
+CONFIGS = {
+    "c1": dict(depth=121, cbb=1, s2=0, batch=1, H=256, W=384, dtype="fp32", name="C1 d121 no-fusion 1x3x256x384"),
+    "c2": dict(depth=121, cbb=1, s2=3, batch=4, H=1280, W=1920, dtype="fp16", name="C2 d121 early-fusion 6ch b4 1280x1920"),
+    "c3": dict(depth=121, cbb=3, s2=3, batch=4, H=1280, W=1920, dtype="fp16", name="C3 d121 mid-fusion(3) b4/GPU 1280x1920"),
+    "c4": dict(depth=169, cbb=3, s2=3, batch=2, H=1280, W=1920, dtype="fp16", name="C4 d169 mid-fusion(3) b2/GPU 1280x1920"),
+    "c5": dict(depth=201, cbb=3, s2=3, batch=8, H=640, W=960, dtype="fp16", name="C5 d201 mid-fusion(3) b8/GPU 640x960"),
+}
+PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def make_config(c):
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    cfg = get_config("/tmp/dmmfods_bench")
+    k, bc, nif = DENSENETS[c["depth"]]
+    cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = k, bc, nif
+    cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = c["cbb"], c["s2"]
+    return cfg
+
+
+def synthetic_batch(c, device, seed):
+    """RGB ~ U[0,255]; LiDAR ~90 % exact zeros, rest U[0,255]; targets (U > 0.9)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    B, H, W = c["batch"], c["H"], c["W"]
+    rgb = torch.rand(B, 3, H, W, device=device, generator=g) * 255.0
+    s2 = max(c["s2"], 1)
+    lidar = torch.rand(B, s2, H, W, device=device, generator=g) * 255.0
+    lidar = lidar * (torch.rand(B, s2, H, W, device=device, generator=g) > 0.9)
+    tgt = (torch.rand(B, 3, H, W, device=device, generator=g) > 0.9).float()
+    return rgb, lidar, tgt
+
+
+def collect_profile(model, plan, K):
+    from dmmfods_amd import _lib
+    L = _lib.lib()
+    classes = {}
+    for which in (0, 1):
+        n = L.dmm_plan_profile_num_ops(plan.handle, which)
+        ms = (C.c_double * n)()
+        passes = C.c_int()
+        _lib.check(L.dmm_plan_profile_collect(plan.handle, which, ms, n, C.byref(passes)))
+        if passes.value == 0:
+            continue
+        for i in range(n):
+            label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+            L.dmm_plan_profile_op(plan.handle, which, i, C.byref(label), C.byref(fl), C.byref(by))
+            cls = (label.value or b"").decode().split("/")[0] or "other"
+            e = classes.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            e["ms"] += ms[i]
+            e["launches"] += passes.value
+            e["flops"] += fl.value * passes.value
+            e["bytes"] += by.value * passes.value
+    return classes
+
+
+def roofline_block(classes, dtype):
+    if not classes:
+        return None, None
+    peak_f = PEAK_MFMA_TFLOPS[dtype] * 1e12
+    peak_b = PEAK_HBM_GBS * 1e9
+    tot_ms = sum(e["ms"] for e in classes.values())
+    ideal_ms = 0.0
+    table = []
+    for cls, e in classes.items():
+        t = e["ms"] / 1e3
+        tf, tb = e["flops"] / peak_f, e["bytes"] / peak_b
+        ideal_ms += max(tf, tb) * 1e3
+        table.append(dict(kernel=cls, ms_total=round(e["ms"], 3), launches=e["launches"],
+                          share=round(e["ms"] / tot_ms, 4) if tot_ms else 0,
+                          tflops=round(e["flops"] / t / 1e12, 2) if t else 0, gbs=round(e["bytes"] / t / 1e9, 1) if t else 0,
+                          bound="mfma" if tf > tb else "hbm", frac=round(max(tf, tb) / t, 4) if t else 0))
+    table.sort(key=lambda r: -r["ms_total"])
+    dom = max(classes.items(), key=lambda kv: kv[1]["ms"])
+    cls, e = dom
+    t = e["ms"] / 1e3
+    tf, tb = e["flops"] / peak_f, e["bytes"] / peak_b
+    if tf > tb:
+        roof = dict(bound="mfma", achieved=round(e["flops"] / t / 1e12, 3), peak=PEAK_MFMA_TFLOPS[dtype], unit="TFLOP/s")
+    else:
+        roof = dict(bound="hbm", achieved=round(e["bytes"] / t / 1e9, 2), peak=PEAK_HBM_GBS, unit="GB/s")
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None
+    roof["kernel"] = cls
+    roof["avg_launch_ms"] = round(e["ms"] / max(e["launches"], 1), 4)
+    roof["alg_flops_per_launch"] = e["flops"] / max(e["launches"], 1)
+    roof["alg_bytes_per_launch"] = e["bytes"] / max(e["launches"], 1)
+    roof["share_of_step"] = round(e["ms"] / tot_ms, 4) if tot_ms else None
+    roof["per_layer_roofline_frac_of_step"] = round(ideal_ms / tot_ms, 4) if tot_ms else None
+    return roof, table
+
+
+def cpu_baseline(max_seconds=25.0):
+    """The CPU oracle (oracle/restatement.py, kind 'port') timed on this host: BASELINE.json configs[0] (C1)."""
+    from oracle import restatement as R
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=0)
+    P = R.make_state(arch, seed=123)
+    tr = R.Trainer(arch, P)
+    rgb, lidar, tgt = R.make_inputs(arch, 1, 256, 384, seed=0)
+    tr.step(rgb, lidar, tgt)  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and time.time() - t_start < max_seconds:
+        t0 = time.time()
+        tr.step(rgb, lidar, tgt)
+        times.append(time.time() - t0)
+    best = min(times)
+    return dict(value=round(1.0 / best, 4), unit="img/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"C1 d121 no-fusion 1x3x256x384 fp32 fwd+BCE+bwd+Adam, {len(times)} steps after 1 warm-up, best {best:.3f} s/step "
+                       f"(= {109.8 / best:.1f} conv GFLOP/s); the GPU workload is 25.4x more conv FLOPs per image")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["fp16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--table", action="store_true", help="also print the per-kernel-class table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from dmmfods_amd import _lib
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    from dmmfods_amd.optim import FusedAdam
+    from dmmfods_amd.parallel import GradAllReduce
+
+    c = dict(CONFIGS[args.config])
+    if args.dtype:
+        c["dtype"] = args.dtype
+    if args.batch:
+        c["batch"] = args.batch
+    torch.manual_seed(123)  # identical weights on every rank (reference agent seed, H:179)
+    model = Dense_U_Net_lidar(make_config(c), compute_dtype=c["dtype"]).to(device).train()
+    opt = FusedAdam(model)
+    reducer = GradAllReduce(model) if distributed else None
+    rgb, lidar, tgt = synthetic_batch(c, device, seed=rank)
+
+    def step():
+        with torch.no_grad():
+            model(rgb, lidar)
+        met = model.loss_backward(tgt)
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return met
+
+    for _ in range(args.warmup):
+        step()
+    plan = model._last[0]
+    if not args.no_profile:
+        _lib.check(_lib.lib().dmm_plan_profile_begin(plan.handle, args.steps))
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        met = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss = met["loss_per_class"].sum().item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = c["batch"] * world * args.steps / elapsed
+        roof, table = (None, None)
+        if not args.no_profile:
+            roof, table = roofline_block(collect_profile(model, plan, args.steps), c["dtype"])
+        fwd_flops_img = plan.flops_forward / c["batch"]
+        out = {
+            "metric": "training images/sec at 1280x1920 RGB+LiDAR",
+            "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if c["dtype"] == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": c["name"], "per_gpu_batch": c["batch"], "global_batch": c["batch"] * world,
+                       "height": c["H"], "width": c["W"], "storage_dtype": c["dtype"], "accumulate": "fp32",
+                       "parallelism": f"dp{world}", "weights": "random-init (reference init, seed 123)",
+                       "fwd_conv_gflop_per_img": round(fwd_flops_img / 1e9, 1),
+                       "train_conv_gflop_per_img": round(3 * fwd_flops_img / 1e9, 1)},
+            "final_loss_sum": loss,
+            "achieved_conv_tflops": round(3 * fwd_flops_img * value / 1e12, 2),
+            "roofline": roof,
+        }
+        if table and args.table:
+            for r in table:
+                print(json.dumps(r), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,9 +89,23 @@ int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float
   return DMM_OK;
 }
 
-static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st) {
+static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_which = -1, size_t ev_offset = 0) {
   const int dt = p->desc.dtype;
   const bool mfma = p->desc.use_mfma != 0;
+  std::vector<void*>* evs = nullptr;
+  if (prof_which >= 0 && p->prof_max_passes > 0 && p->prof_pass[prof_which] < p->prof_max_passes) {
+    auto& sets = p->prof_events[prof_which];
+    const int pass = p->prof_pass[prof_which]++;
+    if ((int)sets.size() <= pass) sets.resize(pass + 1);
+    evs = &sets[pass];
+    const size_t need = ops.size() + ev_offset + 1;
+    while (evs->size() < need) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+      evs->push_back((void*)e);
+    }
+    hipEventRecord((hipEvent_t)(*evs)[ev_offset], st);
+  }
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& o = ops[i];
     hipError_t e = hipSuccess;
@@ -111,6 +125,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st) {
       default: return fail(DMM_ERR_STATE, "unknown op");
     }
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
+    if (evs) hipEventRecord((hipEvent_t)(*evs)[ev_offset + i + 1], st);
   }
   return DMM_OK;
 }
@@ -127,7 +142,7 @@ int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_
     else { o.cv.src1 = stream_2; o.cv.src2 = nullptr; }
   }
   ops[training ? plan->logits_op_train : plan->logits_op_eval].c.logits = logits_out;
-  return run_ops(plan, ops, (hipStream_t)stream);
+  return run_ops(plan, ops, (hipStream_t)stream, training ? 0 : -1);
 }
 
 int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream) {
@@ -136,7 +151,7 @@ int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* tar
   Op& b = plan->bwd[plan->bce_op];
   b.bce.logits = logits;
   b.bce.target = target;
-  int rc = run_ops(plan, plan->bwd, (hipStream_t)stream);
+  int rc = run_ops(plan, plan->bwd, (hipStream_t)stream, 1);
   if (rc) return rc;
   if (metrics_out) HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return DMM_OK;
@@ -154,6 +169,48 @@ int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream) {
   HIPCHK(launch_convert_input(cv, plan->desc.dtype, st));
   std::vector<Op> rest(plan->bwd.begin() + plan->bce_op + 1, plan->bwd.end());
   return run_ops(plan, rest, st);
+}
+
+int dmm_plan_profile_begin(dmm_plan* plan, int max_passes) {
+  if (!plan) return fail(DMM_ERR_INVALID, "null plan");
+  plan->prof_max_passes = max_passes;
+  plan->prof_pass[0] = plan->prof_pass[1] = 0;
+  return DMM_OK;
+}
+
+int dmm_plan_profile_num_ops(const dmm_plan* plan, int which) {
+  if (!plan || which < 0 || which > 1) return 0;
+  return (int)(which == 0 ? plan->fwd_train.size() : plan->bwd.size());
+}
+
+int dmm_plan_profile_op(const dmm_plan* plan, int which, int index, const char** label, double* flops, double* bytes) {
+  if (!plan || which < 0 || which > 1) return fail(DMM_ERR_INVALID, "bad argument");
+  const std::vector<Op>& ops = which == 0 ? plan->fwd_train : plan->bwd;
+  if (index < 0 || index >= (int)ops.size()) return fail(DMM_ERR_INVALID, "op index out of range");
+  if (label) *label = ops[index].label;
+  if (flops) *flops = ops[index].flops;
+  if (bytes) *bytes = ops[index].bytes;
+  return DMM_OK;
+}
+
+/* Sum of per-op durations (ms) over the recorded passes; the caller must have synchronised the stream. */
+int dmm_plan_profile_collect(dmm_plan* plan, int which, double* ms_sum, int n, int* passes) {
+  if (!plan || which < 0 || which > 1 || !ms_sum) return fail(DMM_ERR_INVALID, "bad argument");
+  const int nops = dmm_plan_profile_num_ops(plan, which);
+  if (n < nops) return fail(DMM_ERR_INVALID, "buffer too small");
+  for (int i = 0; i < nops; ++i) ms_sum[i] = 0;
+  int np = 0;
+  for (auto& evs : plan->prof_events[which]) {
+    if ((int)evs.size() < nops + 1 || np >= plan->prof_pass[which]) continue;
+    for (int i = 0; i < nops; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, (hipEvent_t)evs[i], (hipEvent_t)evs[i + 1]) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventElapsedTime failed");
+      ms_sum[i] += ms;
+    }
+    ++np;
+  }
+  if (passes) *passes = np;
+  return DMM_OK;
 }
 
 int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream) {

@@ -14,6 +14,7 @@
 #include "plan.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -367,6 +368,43 @@ struct Builder {
     ops->back().kind = kind;
     return ops->back();
   }
+  void tag(Op& o, const char* cls, const std::string& layer, double flops, double bytes) {
+    snprintf(o.label, sizeof(o.label), "%s/%s", cls, layer.c_str());
+    o.flops = flops;
+    o.bytes = bytes;
+  }
+  static const char* ncls(const char* base, int npad, char* buf) {
+    snprintf(buf, 32, "%s.n%d", base, npad % 128 == 0 ? 128 : (npad % 64 == 0 ? 64 : 32));
+    return buf;
+  }
+  std::string short_name(const std::string& w) const {
+    std::string s = w;
+    const char* cuts[] = {"features.", "stream_2_features.", "decoder.", "dec_out_to_heat_maps.", ".weight", "denseblock", "denselayer", "Transposed_Convolution"};
+    const char* reps[] = {"f.", "s2.", "d.", "h.", "", "b", "l", "TC"};
+    for (int i = 0; i < 8; ++i) {
+      size_t p;
+      while ((p = s.find(cuts[i])) != std::string::npos) s.replace(p, strlen(cuts[i]), reps[i]);
+    }
+    return s;
+  }
+  double conv_flops(const ConvRec& c, size_t nphases) const {
+    const double px = (double)c.B * c.Ho * c.Wo * (c.seg[0].mode == G_POOL2 ? 4.0 : 1.0);
+    const double f = c.transposed ? 2.0 * px * c.N * c.Kin * 9.0 : 2.0 * px * c.N * c.Kin * c.R * c.S;
+    return f / (double)nphases;
+  }
+  double src_bytes(const ConvRec& c) const {
+    double b = 0;
+    for (int s = 0; s < c.nseg; ++s) {
+      const Buf& sb = bufs[c.seg[s].buf];
+      b += (double)sb.B * sb.H * sb.W * c.seg[s].C * esz;
+    }
+    return b;
+  }
+  double out_bytes(const ConvRec& c) const {
+    const Buf& ob = bufs[c.obuf];
+    return (double)ob.B * ob.H * ob.W * rup(c.N, 8) * (c.epi == EPI_LOGITS ? 4 : esz);
+  }
+  double w_bytes(const ConvRec& c) const { return (double)c.N * c.Kin * c.R * c.S * esz; }
   const uint8_t* xat(int buf, int ch) const { return bufs[buf].x + (size_t)ch * esz; }
   uint8_t* gat(int buf, int ch) const { return bufs[buf].g ? bufs[buf].g + (size_t)ch * esz : nullptr; }
 
@@ -427,6 +465,12 @@ struct Builder {
       a.ldo = ob.ld; a.Hout = ob.H; a.Wout = ob.W;
       a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
       if (c.stats && ob.ssum) { a.stat_sum = ob.ssum + c.och0; a.stat_sq = ob.ssq + c.och0; }
+      {
+        char cb[32];
+        const double np = (double)c.phases.size();
+        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : "igemm.store", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+            (src_bytes(c) + out_bytes(c)) / np + w_bytes(c) / np);
+      }
       if (c.epi == EPI_LOGITS) {
         if (training) P.logits_op_train = (int)ops->size() - 1; else P.logits_op_eval = (int)ops->size() - 1;
       }
@@ -481,6 +525,13 @@ struct Builder {
       a.N = c.N; a.Npad = pd.Npad;
       a.Hout = ob.H; a.Wout = ob.W; a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
       a.dpack = (float*)pd.dpack;
+      {
+        char cb[32];
+        const double np = (double)c.phases.size();
+        // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
+        tag(o, ncls("wgrad", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+            (src_bytes(c) + (ob.q ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
+      }
     }
     // ---- data gradients with fused BN+ReLU backward ----
     for (int s = 0; s < c.nseg; ++s) {
@@ -514,6 +565,14 @@ struct Builder {
       a.red1 = bn.red1 + sr.bn_c0; a.red2 = bn.red2 + sr.bn_c0;
       a.accumulate = sb.ginit ? 1 : 0;
       a.pool2 = pool2;
+      {
+        char cb[32];
+        // reads: output gradient (+ forward output for the correction), x for the ReLU mask, (old gradient); writes gradient
+        const double srcb = (double)sb.B * sb.H * sb.W * sr.C * esz;
+        const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
+        tag(o, ncls("igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
+            (ob.q ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
+      }
       sb.ginit = true;
     }
     int done = -1;
@@ -535,6 +594,7 @@ struct Builder {
     a.out = (void*)xat(p.obuf, p.och0); a.ldo = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
     a.argmax = p.argmax;
     a.stat_sum = ob.ssum + p.och0; a.stat_sq = ob.ssq + p.och0;
+    tag(o, "maxpool.fwd", "pool0", 0, ((double)yb.B * yb.H * yb.W + (double)ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
   }
   void emit_pool_bwd(PoolRec& p) {
     Op& o = push(OP_POOLBWD);
@@ -549,6 +609,7 @@ struct Builder {
     a.argmax = p.argmax;
     a.gy0 = yb.g;
     a.red1 = bns[p.bn].red1; a.red2 = bns[p.bn].red2;
+    tag(o, "maxpool.bwd", "pool0", 0, (2.0 * yb.B * yb.H * yb.W + 2.0 * ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
     yb.ginit = true;
     emit_bn_bwd_finalize(p.bn);
   }
@@ -777,6 +838,7 @@ struct Builder {
       a.B = bufs[buf].B; a.H = bufs[buf].H; a.W = bufs[buf].W;
       a.stat_sum = bufs[buf].ssum; a.stat_sq = bufs[buf].ssq;
       o.epi = which;  // 0: (s1), 1: (s1,s2), 2: (s2)
+      tag(o, "convert", "input", 0, (double)a.B * a.H * a.W * ((c1 + c2) * 4.0 + 8.0 * esz));
       idx.push_back((int)ops->size() - 1);
     };
     if (g.fusion == 0) one(in1, g.s1, 0, 0);
@@ -791,6 +853,7 @@ struct Builder {
     o.pk.ndesc = (int)P.packs.size();
     o.pk.total_rows = total_rows;
     o.pk.grad_scale = 1.0f / d.loss_scale;
+    tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
   }
 
   PackDesc* pack_dev = nullptr;
@@ -842,6 +905,7 @@ struct Builder {
       a.out = P.metrics;
       a.B = d.batch; a.NC = g.nc; a.H = d.height; a.W = d.width;
       a.thr = d.iou_threshold; a.loss_scale = d.loss_scale;
+      tag(o, "bce", "loss", 0, (double)a.B * a.H * a.W * (a.NC * 8.0 + 8.0 * esz));
       P.bce_op = (int)ops->size() - 1;
       P.bce_only = o;
       P.bce_only.bce.dlogits = nullptr;

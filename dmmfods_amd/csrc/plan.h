@@ -40,6 +40,9 @@ struct PackArgs { const PackDesc* descs; const int* prefix; int ndesc, total_row
 struct Op {
   int kind;
   int epi;
+  double flops;    // algorithmic 2*MACs of this launch (reference formulation)
+  double bytes;    // algorithmic HBM bytes: every operand read once, every result written once
+  char label[56];  // kernel class / layer
   union {
     MemsetArgs ms;
     CopyArgs cp;
@@ -53,7 +56,7 @@ struct Op {
     BceArgs bce;
     PackArgs pk;
   };
-  Op() : kind(0), epi(0) {}
+  Op() : kind(0), epi(0), flops(0), bytes(0) { label[0] = 0; }
 };
 
 }  // namespace dmm
@@ -78,4 +81,8 @@ struct dmm_plan {
   size_t metrics_bytes = 0;
   std::vector<dmm::PackDesc> packs;
   std::vector<int> pack_prefix;
+  // profiling: per-op events on the launch stream, one set per recorded pass
+  int prof_max_passes = 0;
+  int prof_pass[2] = {0, 0};                       // passes recorded for [0] training forward, [1] backward
+  std::vector<std::vector<void*>> prof_events[2];  // [which][pass] -> nops+1 events
 };

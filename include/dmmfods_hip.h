@@ -101,6 +101,14 @@ int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* tar
  * loss on the returned logits (reference: loss.backward(...), agents/Dense_U_Net_lidar_Agent.py:264). */
 int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream);
 
+/* Per-launch timing with HIP events recorded on the launch stream (used by bench.py for the roofline block).
+ * which: 0 = training forward, 1 = loss + backward.  profile_begin(plan, n) arms recording for the next n passes of
+ * each; profile_collect sums per-op milliseconds over the recorded passes (synchronise the stream first). */
+int dmm_plan_profile_begin(dmm_plan* plan, int max_passes);
+int dmm_plan_profile_num_ops(const dmm_plan* plan, int which);
+int dmm_plan_profile_op(const dmm_plan* plan, int which, int index, const char** label, double* flops, double* bytes);
+int dmm_plan_profile_collect(dmm_plan* plan, int which, double* ms_sum, int n, int* passes);
+
 /* Loss + metrics only (validation). */
 int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream);
 

@@ -241,9 +241,25 @@ def make_inputs(arch: Arch, batch: int, height: int, width: int, seed: int = 0):
 # --------------------------------------------------------------------------------------
 # functional forward
 # --------------------------------------------------------------------------------------
+class _RoundSTE(torch.autograd.Function):
+    """Round to a storage dtype in forward, identity in backward (emulates the HIP path's fp16 storage of
+    activations and packed weights while keeping fp32/fp64 arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class _Ctx:
-    def __init__(self, P: Dict[str, torch.Tensor], training: bool):
-        self.P, self.training = P, training
+    def __init__(self, P: Dict[str, torch.Tensor], training: bool, storage=None):
+        self.P, self.training, self.storage = P, training, storage
+
+    def st(self, x):
+        return x if self.storage is None else _RoundSTE.apply(x, self.storage)
 
     def bn_relu(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
         P = self.P
@@ -255,8 +271,9 @@ class _Ctx:
             P[prefix + ".num_batches_tracked"] += 1
         return F.relu(y)
 
-    def conv(self, x, key, stride=1, padding=0):
-        return F.conv2d(x, self.P[key + ".weight"], None, stride, padding)
+    def conv(self, x, key, stride=1, padding=0, store=True):
+        y = F.conv2d(x, self.st(self.P[key + ".weight"]), None, stride, padding)
+        return self.st(y) if store else y
 
 
 def _dense_block(ctx: _Ctx, x: torch.Tensor, prefix: str, nlayers: int) -> torch.Tensor:
@@ -270,19 +287,26 @@ def _dense_block(ctx: _Ctx, x: torch.Tensor, prefix: str, nlayers: int) -> torch
 
 
 def _transition(ctx: _Ctx, x: torch.Tensor, prefix: str) -> torch.Tensor:
-    return F.avg_pool2d(ctx.conv(ctx.bn_relu(x, prefix + ".norm"), prefix + ".conv"), 2, 2)
+    return ctx.st(F.avg_pool2d(ctx.conv(ctx.bn_relu(x, prefix + ".norm"), prefix + ".conv", store=False), 2, 2))
 
 
 def _stem(ctx: _Ctx, x: torch.Tensor, prefix: str):
     y = ctx.bn_relu(ctx.conv(x, prefix + ".conv0", stride=2, padding=3), prefix + ".norm0")
-    return y, F.max_pool2d(y, 3, 2, 1)
+    return y, ctx.st(F.max_pool2d(y, 3, 2, 1))
 
 
 def forward(P: Dict[str, torch.Tensor], arch: Arch, stream_1: torch.Tensor, stream_2: Optional[torch.Tensor],
-            training: bool = True) -> torch.Tensor:
+            training: bool = True, storage=None) -> torch.Tensor:
     """Logits (B, num_classes, H, W).  BN running stats / num_batches_tracked in ``P`` are updated in
-    place when ``training`` (as nn.BatchNorm2d does).  Mirrors M:210-267."""
-    ctx = _Ctx(P, training)
+    place when ``training`` (as nn.BatchNorm2d does).  Mirrors M:210-267.
+
+    ``storage`` (e.g. torch.float16) rounds inputs, packed weights and every tensor the HIP path stores
+    (conv / pool / transposed-conv outputs) to that dtype with straight-through gradients; the arithmetic stays
+    in the tensors' own dtype.  It is the yardstick for the fp16 build: what fp16 storage alone does to the result."""
+    ctx = _Ctx(P, training, storage)
+    stream_1 = ctx.st(stream_1)
+    if stream_2 is not None:
+        stream_2 = ctx.st(stream_2)
     fusion = arch.fusion
     nb = len(arch.block_config)
     if fusion == "no":
@@ -321,13 +345,13 @@ def forward(P: Dict[str, torch.Tensor], arch: Arch, stream_1: torch.Tensor, stre
         p = f"decoder.Transposed_Convolution_Sequence_{j}"
         x = ctx.bn_relu(ctx.conv(ctx.bn_relu(x, p + ".norm0"), p + ".conv_reduce"), p + ".norm1")
         hw = sizes.pop()
-        x = F.conv_transpose2d(x, P[f"decoder.Transposed_Convolution_{j}.weight"], None, stride=2, padding=1,
-                               output_padding=1)
+        x = ctx.st(F.conv_transpose2d(x, ctx.st(P[f"decoder.Transposed_Convolution_{j}.weight"]), None, stride=2,
+                                      padding=1, output_padding=1))
         assert tuple(x.shape[2:]) == tuple(hw)
     x = F.interpolate(x, scale_factor=2, mode="nearest")
     x = torch.cat((x, skips.pop()), 1)  # raw input again (M:264)
     x = ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm0"), "dec_out_to_heat_maps.refine0", padding=1)
-    x = ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm1"), "dec_out_to_heat_maps.refine1", padding=2)
+    x = ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm1"), "dec_out_to_heat_maps.refine1", padding=2, store=False)
     return x
 
 
@@ -363,8 +387,8 @@ class Trainer:
     zero_grad, backward(ones), Adam(lr 1e-3, betas .9/.999, eps 1e-8, wd 0, amsgrad False; H:146-159)."""
 
     def __init__(self, arch: Arch, P: Dict[str, torch.Tensor], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 iou_threshold: float = 0.7):
-        self.arch, self.P, self.thr = arch, P, iou_threshold
+                 iou_threshold: float = 0.7, storage=None):
+        self.arch, self.P, self.thr, self.storage = arch, P, iou_threshold, storage
         self.leaves = leaf_params(P, arch)
         for _, t in self.leaves:
             t.requires_grad_(True)
@@ -372,7 +396,7 @@ class Trainer:
                                     amsgrad=False)
 
     def step(self, rgb, lidar, target, do_update: bool = True):
-        logits = forward(self.P, self.arch, rgb, lidar, training=True)
+        logits = forward(self.P, self.arch, rgb, lidar, training=True, storage=self.storage)
         loss = bce_with_logits(logits, target)
         loss_per_class = loss.detach().sum(dim=(0, 2, 3))
         iou = iou_whole_img_batch(logits.detach(), target, self.thr)
@@ -385,7 +409,7 @@ class Trainer:
 
     def evaluate(self, rgb, lidar, target):
         with torch.no_grad():
-            logits = forward(self.P, self.arch, rgb, lidar, training=False)
+            logits = forward(self.P, self.arch, rgb, lidar, training=False, storage=self.storage)
             loss = bce_with_logits(logits, target)
             return dict(logits=logits, loss_per_class=loss.sum(dim=(0, 2, 3)),
                         iou=iou_whole_img_batch(logits, target, self.thr),

@@ -1,0 +1,153 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares, the plan's
+state_dict layout equals the reference's (golden G1), host-side error behaviour, and the data-parallel
+gradient exchange (world_size 2, gloo)."""
+import ctypes as C
+import gzip
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = {"no": (1, 0), "early": (1, 3), "mid2": (2, 3), "mid3": (3, 3), "mid4": (4, 3)}
+DENSENETS = {121: (32, (6, 12, 24, 16), 64), 161: (48, (6, 12, 36, 24), 96), 169: (32, (6, 12, 32, 32), 64),
+             201: (32, (6, 12, 48, 32), 64)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from dmmfods_amd import _lib
+    return _lib
+
+
+def _cfg(depth, variant):
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    cfg = get_config("/tmp/dmm_test")
+    k, bc, nif = DENSENETS[depth]
+    cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = k, bc, nif
+    cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = VARIANTS[variant]
+    return cfg
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "dmmfods_hip.h")).read()
+    declared = set(re.findall(r"\b(dmm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dmm_status"}
+    L = lib.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(lib.EXPORTS) <= declared
+
+
+def test_state_dict_layout_matches_reference(lib, golden_dir):
+    from dmmfods_amd.graphs.models import Dense_U_Net_lidar as M
+    g1 = json.load(gzip.open(os.path.join(golden_dir, "g1_topology.json.gz"), "rt"))
+    for depth in (121, 169, 201, 161):
+        for v in VARIANTS:
+            factory = getattr(M, f"densenet{depth}_u_lidar")
+            model = factory(pretrained=False, config=_cfg(depth, v))
+            sd = model.state_dict()
+            blob = ";".join(f"{k}:{','.join(map(str, t.shape))}" for k, t in sd.items()).encode()
+            ent = g1[f"d{depth}_{v}"]
+            assert hashlib.sha256(blob).hexdigest() == ent["sha256"], (depth, v)
+            assert model.num_params == ent["num_params"]
+            assert model.fusion == ent["fusion"]
+            assert [k for k, _ in model.named_parameters()] == [k for k, s in (ent.get("keys") or [[k, None] for k, _ in model.named_parameters()])
+                                                                if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+
+def test_parameters_are_arena_views_and_survive_load(lib):
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import densenet121_u_lidar
+    m = densenet121_u_lidar(config=_cfg(121, "mid3"))
+    base = m.param_arena.data_ptr()
+    off = 0
+    for p in m.parameters():
+        assert p.data_ptr() == base + 4 * off
+        off += p.numel()
+    assert off == m.param_arena.numel() == 23567564
+    sd = {k: torch.full_like(v, 0.5) if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert float(m.param_arena.min()) == 0.5 and float(m.param_arena.max()) == 0.5
+    # reference init statistics: conv kaiming_normal (std sqrt(2/fan_in)), ConvTranspose default (std ~ sqrt(1/(3 fan_in)))
+    m2 = densenet121_u_lidar(config=_cfg(121, "no"))
+    w = m2.features.denseblock1.denselayer1.conv2.weight
+    assert abs(w.std().item() / (2.0 / (128 * 9)) ** 0.5 - 1) < 0.05
+    wt = m2.decoder.Transposed_Convolution_1.weight
+    assert abs(wt.std().item() / (1.0 / (3 * 1024 * 9)) ** 0.5 - 1) < 0.05
+
+
+def test_error_behaviour_matches_reference(lib):
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    cfg = _cfg(121, "no")
+    cfg.model.concat_before_block_num = 7
+    with pytest.raises(AttributeError):     # reference M:65
+        Dense_U_Net_lidar(cfg)
+    m = Dense_U_Net_lidar(_cfg(121, "no"))
+    with pytest.raises(RuntimeError, match="GPU only"):   # no CPU fallback
+        m(torch.zeros(1, 3, 64, 64), None)
+    d = lib.ModelDesc(growth_rate=32, num_blocks=4, num_init_features=64, bn_size=4, num_classes=3, concat_before_block_num=1,
+                      stream_1_in_channels=3, stream_2_in_channels=0, batch=1, height=100, width=100, dtype=0, loss_scale=1.0,
+                      bn_momentum=0.1, bn_eps=1e-5, iou_threshold=0.7, use_mfma=1)
+    for i, v in enumerate((6, 12, 24, 16)):
+        d.block_config[i] = v
+    h = C.c_void_p()
+    with pytest.raises(ValueError):         # reference: ValueError from ConvTranspose2d(output_size=...) (M:261)
+        lib.check(lib.lib().dmm_plan_create(C.byref(d), C.byref(h)))
+
+
+def test_plan_flops_match_survey(lib):
+    L = lib.lib()
+    for (cbb, s2, want) in ((1, 3, 938.7), (3, 3, 1133.1)):
+        d = lib.ModelDesc(growth_rate=32, num_blocks=4, num_init_features=64, bn_size=4, num_classes=3, concat_before_block_num=cbb,
+                          stream_1_in_channels=3, stream_2_in_channels=s2, batch=4, height=1280, width=1920, dtype=1, loss_scale=1.0,
+                          bn_momentum=0.1, bn_eps=1e-5, iou_threshold=0.7, use_mfma=1)
+        for i, v in enumerate((6, 12, 24, 16)):
+            d.block_config[i] = v
+        h = C.c_void_p()
+        lib.check(L.dmm_plan_create(C.byref(d), C.byref(h)))
+        assert abs(L.dmm_plan_forward_flops(h) / 4 / 1e9 - want) < 0.5
+        assert L.dmm_plan_workspace_bytes(h) < 40 * 2**30
+        L.dmm_plan_destroy(h)
+
+
+def test_config_fields_match_reference():
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import create_config, get_config
+    cfg = get_config("/tmp/x")
+    assert cfg.model.growth_rate == 32 and tuple(cfg.model.block_config) == (6, 12, 24, 16)
+    assert cfg.model.concat_before_block_num == 2 and cfg.model.stream_2_in_channels == 1
+    assert cfg.optimizer.learning_rate == 1e-3 and cfg.optimizer.beta2 == 0.999 and cfg.agent.iou_threshold == 0.7
+    assert cfg.agent.checkpoint.state_dict == "state_dict" and cfg.agent.seed == 123
+    assert set(create_config("/tmp/x")) == {"dir", "scripts", "model", "loss", "loader", "optimizer", "dataset", "agent"}
+
+
+_DP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from dmmfods_amd.parallel import GradAllReduce
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+r = GradAllReduce(arena, bucket_bytes=1024)   # 256-element buckets -> 4 collectives
+r.all_reduce()
+want = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
+assert torch.equal(arena, want), (rank, arena[:5])
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_grad_allreduce_sum_gloo_world2(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

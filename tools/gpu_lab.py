@@ -129,7 +129,7 @@ def run_kernels():
     return ok
 
 
-def run_model(variants=("no", "early", "mid3", "mid2", "mid4"), dtypes=("fp32", "fp16"), mfma=True):
+def run_model(variants=("no", "early", "mid3", "mid2", "mid4"), dtypes=("fp32", "fp16"), mfma=True, loss_scale=None):
     from oracle import restatement as R
     from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
     from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
@@ -149,26 +149,39 @@ def run_model(variants=("no", "early", "mid3", "mid2", "mid4"), dtypes=("fp32", 
             outs[odt] = (o, {k: t.grad.clone() for k, t in tr.leaves}, P)
         o64, g64, P64 = outs[torch.float64]
         o32, g32, _ = outs[torch.float32]
+        # fp16-storage emulation (fp64 arithmetic, fp16 rounding where the HIP path stores fp16)
+        Ph = {k: (t.double() if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=123).items()}
+        trh = R.Trainer(arch, Ph, storage=torch.float16)
+        rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=0)
+        oh = trh.step(rgb.double(), lidar.double(), tgt.double(), do_update=False)
+        gh = {k: t.grad.clone() for k, t in trh.leaves}
         for dts in dtypes:
             try:
                 cfg = get_config("/tmp/dmm")
                 cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = 8, (2, 2, 2, 2), 16
                 cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = cbb, s2
-                model = Dense_U_Net_lidar(cfg, compute_dtype=dts, use_mfma=mfma)
+                model = Dense_U_Net_lidar(cfg, compute_dtype=dts, use_mfma=mfma, loss_scale=loss_scale)
                 model.load_state_dict(R.make_state(arch, seed=123))
                 model = model.to(DEV).train()
                 rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=0)
                 logits = model(rgb.to(DEV), lidar.to(DEV))
                 met = model.loss_backward(tgt.to(DEV))
                 torch.cuda.synchronize()
+                if dts == "fp16":  # judge the fp16 build against fp16-storage emulation
+                    o64, g64 = oh, gh
+                else:
+                    o64, g64 = outs[torch.float64][0], outs[torch.float64][1]
                 e_log = relerr(logits.detach().cpu(), o64["logits"])
                 n_log = relerr(o32["logits"], o64["logits"])
                 e_loss = relerr(met["loss_per_class"].cpu(), o64["loss_per_class"])
                 iou_ok = torch.allclose(met["iou_per_instance_per_class"].cpu(), o64["iou"].float(), atol=2e-2, equal_nan=True)
                 worst = []
+                num = den = 0.0
                 for k, p in model.named_parameters():
                     ref = g64[k]
                     s = ref.abs().max().clamp_min(1e-30)
+                    num += (p.grad.detach().cpu().double() - ref).pow(2).sum().item()
+                    den += ref.pow(2).sum().item()
                     e = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
                     n = ((g32[k].double() - ref).abs().max() / s).item()
                     worst.append((e, n, k))
@@ -180,7 +193,7 @@ def run_model(variants=("no", "early", "mid3", "mid2", "mid4"), dtypes=("fp32", 
                 bad = e_log > tol or worst[0][0] > (3e-3 if dts == "fp32" else 0.2) or not iou_ok
                 ok &= not bad
                 print(f"{'FAIL' if bad else 'ok  '} model {v:6s} {dts} mfma={int(mfma)} logits={e_log:.2e} (cpu32 {n_log:.1e}) loss={e_loss:.2e} "
-                      f"iou_ok={iou_ok} rm={e_rm:.1e} rv={e_rv:.1e}", flush=True)
+                      f"iou_ok={iou_ok} rm={e_rm:.1e} rv={e_rv:.1e} gradL2={(num / den) ** 0.5:.2e} ls={loss_scale}", flush=True)
                 for e, n, k in worst[:6]:
                     print(f"        grad err {e:.2e} (cpu32 {n:.1e}) {k}", flush=True)
             except Exception:
@@ -198,6 +211,10 @@ if __name__ == "__main__":
         ok &= run_kernels()
     if "model" in what:
         ok &= run_model()
+    if "scale" in what:
+        for ls in (1.0, 64.0, 4096.0, 1.0 / 64):
+            run_model(variants=("no",), dtypes=("fp16",), loss_scale=ls)
+        run_model(variants=("no",), dtypes=("fp16",), mfma=False)
     if "model_scalar" in what:
         ok &= run_model(variants=("no",), dtypes=("fp32",), mfma=False)
     print(f"LAB {'PASS' if ok else 'FAIL'} in {time.time() - t0:.1f}s", flush=True)
