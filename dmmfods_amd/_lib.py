@@ -42,6 +42,13 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C dmmfods_amd/csrc`).  dmmfods_amd has no CPU fallback.")
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Device pointers and streams are only
+    # meaningful inside ONE runtime, so make sure torch's copy is the one already loaded when our library's
+    # NEEDED libamdhip64.so.7 is resolved (same SONAME -> the loader reuses it).
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     L.dmm_last_error.restype = C.c_char_p

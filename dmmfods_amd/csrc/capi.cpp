@@ -67,12 +67,12 @@ int dmm_plan_tensor_info(const dmm_plan* plan, int index, const char** name, int
 
 int64_t dmm_plan_num_params(const dmm_plan* plan) { return plan ? plan->nparams : 0; }
 int64_t dmm_plan_num_buffer_elems(const dmm_plan* plan) { return plan ? plan->nbuf : 0; }
-size_t dmm_plan_workspace_bytes(const dmm_plan* plan) { return plan ? plan->zero_bytes + plan->main_bytes : 0; }
+size_t dmm_plan_workspace_bytes(const dmm_plan* plan) { return plan ? plan->zero_bytes + plan->zero_bwd_bytes + plan->main_bytes : 0; }
 double dmm_plan_forward_flops(const dmm_plan* plan) { return plan ? plan->fwd_flops : 0; }
 
 int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float* params, float* grads, float* buffers) {
   if (!plan || !workspace || !params || !grads || !buffers) return fail(DMM_ERR_INVALID, "null argument");
-  if (workspace_bytes < plan->zero_bytes + plan->main_bytes) return fail(DMM_ERR_INVALID, "workspace too small");
+  if (workspace_bytes < dmm_plan_workspace_bytes(plan)) return fail(DMM_ERR_INVALID, "workspace too small");
   if ((uintptr_t)workspace % 256) return fail(DMM_ERR_INVALID, "workspace must be 256-byte aligned");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMM_ERR_NO_DEVICE, "no HIP device");
@@ -166,6 +166,7 @@ int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream) {
   memset(&cv, 0, sizeof(cv));
   cv.src1 = dlogits; cv.C1 = b.NC; cv.dst = b.dlogits; cv.B = b.B; cv.H = b.H; cv.W = b.W;
   cv.scale = plan->desc.loss_scale;
+  HIPCHK(hipMemsetAsync(plan->bwd[0].ms.p, 0, plan->bwd[0].ms.bytes, st));
   HIPCHK(launch_convert_input(cv, plan->desc.dtype, st));
   std::vector<Op> rest(plan->bwd.begin() + plan->bce_op + 1, plan->bwd.end());
   return run_ops(plan, rest, st);

@@ -40,7 +40,7 @@ struct IgemmSmem {
   static constexpr int MAIN = 2 * (A_BYTES + B_BYTES);
   static constexpr int STAGE_T = BM * STAGE_PITCH_T * (int)sizeof(T);
   static constexpr int STAGE_F = BM * STAGE_PITCH_F * 4;
-  static constexpr int EXTRA = BM * 4 + 2 * BN * 4;  // rowpix + reduction scratch
+  static constexpr int EXTRA = BM * 4 + 2 * BN * 8;  // rowpix + fp64 reduction scratch
   static constexpr int bytes(int epi) {
     int st = (epi == EPI_STORE) ? STAGE_T : STAGE_F;
     int m = MAIN > st ? MAIN : st;
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int MAINB = (SM::MAIN > (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F)) ? SM::MAIN
                         : (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F);
   int* rowpix = (int*)(smem + MAINB);
-  float* red = (float*)(smem + MAINB + BM * 4);
+  // Per-channel reductions are carried in fp64 from the first add: BatchNorm backward subtracts per-channel means of
+  // the gradient, and an error of 1e-7*sum|dz| in that mean is a coherent offset that the next weight-gradient GEMM
+  // amplifies over all pixels (torch's CPU BatchNorm accumulates in double for the same reason).
+  double* red = (double*)(smem + MAINB + BM * 4);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     row_to_byx(m < a.M ? m : 0, a.Ho, a.Wo, pb, py_, px_);
     rowpix[tid] = m < a.M ? (pb * a.Hout + py_ * a.ostride + a.py) * a.Wout + px_ * a.ostride + a.px : -1;
   }
-  if (tid < 2 * BN) red[tid] = 0.f;
+  if (tid < 2 * BN) red[tid] = 0.0;
 
   int total = 0;
   for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
@@ -207,9 +210,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int cv = tid % NCV, rr = tid / NCV;
   const int n = n0 + cv * SLOT;
   const bool colvalid = n < a.N;
-  float s1[SLOT], s2[SLOT];
+  double s1[SLOT], s2[SLOT];
 #pragma unroll
-  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
 
   if (EPI == EPI_STORE) {
     const T* Cs = (const T*)smem;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       float f[SLOT];
       vec_to_f32<T>(v, f);
 #pragma unroll
-      for (int i = 0; i < SLOT; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
+      for (int i = 0; i < SLOT; ++i) { const double v = (double)f[i]; s1[i] += v; s2[i] += v * v; }
     }
     if (a.stat_sum == nullptr) return;
   } else {  // EPI_BNBWD
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < SLOT; ++i) {
           const float dz = (fmaf(xf[i], sc[i], sh[i]) > 0.f) ? av[i] * wgt : 0.f;
-          s1[i] += dz;
-          s2[i] = fmaf(dz, xf[i], s2[i]);
+          s1[i] += (double)dz;
+          s2[i] += (double)dz * (double)xf[i];
           gf[i] = (a.accumulate ? gf[i] : 0.f) + sc[i] * dz;
         }
         *(V*)(g + p * a.ldo + n) = f32_to_vec<T>(gf);
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   if (tid < BN && n0 + tid < a.N) {
     double* d1 = (EPI == EPI_STORE) ? a.stat_sum : a.red1;
     double* d2 = (EPI == EPI_STORE) ? a.stat_sq : a.red2;
-    atomic_add_f64(d1 + n0 + tid, (double)red[tid]);
-    atomic_add_f64(d2 + n0 + tid, (double)red[BN + tid]);
+    atomic_add_f64(d1 + n0 + tid, red[tid]);
+    atomic_add_f64(d2 + n0 + tid, red[BN + tid]);
   }
 }
 

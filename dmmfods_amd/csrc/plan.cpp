@@ -262,8 +262,8 @@ struct Builder {
   Geo g;
   const int dtype, esz, SLOT, BK;
   const bool sizing;
-  uint8_t *zbase, *wbase;
-  Bump Z, W;
+  uint8_t *zbase, *zbbase, *wbase;
+  Bump Z, ZB, W;  // Z: forward accumulators (BN statistics); ZB: backward accumulators (reductions, q/r, packed dW, metrics)
   std::map<std::string, const TensorInfo*> tmap;
   std::vector<Buf> bufs;
   std::vector<Bn> bns;
@@ -279,11 +279,13 @@ struct Builder {
       : P(p), d(p.desc), g(p.desc), dtype(p.desc.dtype), esz((int)dtype_size(p.desc.dtype)), SLOT(16 / esz), BK(4 * (16 / esz)),
         sizing(sizing_) {
     zbase = ws;
-    wbase = sizing ? nullptr : ws + ((p.zero_bytes + 255) / 256 * 256);
+    zbbase = sizing ? nullptr : ws + p.zero_bytes;
+    wbase = sizing ? nullptr : ws + p.zero_bytes + p.zero_bwd_bytes;
     for (auto& t : P.tensors) tmap[t.name] = &t;
   }
 
   template <typename U> U* zptr(size_t n) { return (U*)((uintptr_t)zbase + Z.take(n * sizeof(U))); }
+  template <typename U> U* zbptr(size_t n) { return (U*)((uintptr_t)zbbase + ZB.take(n * sizeof(U))); }
   template <typename U> U* wptr(size_t n) { return (U*)((uintptr_t)wbase + W.take(n * sizeof(U))); }
   int rup(int v, int m) const { return (v + m - 1) / m * m; }
 
@@ -300,7 +302,7 @@ struct Builder {
     b.x = wptr<uint8_t>(n * esz);
     if (grad) b.g = wptr<uint8_t>(n * esz);
     if (stats) { b.ssum = zptr<double>(ld); b.ssq = zptr<double>(ld); }
-    if (grad) { b.q = zptr<float>(ld + 8); b.r = zptr<float>(ld + 8); }
+    if (grad) { b.q = zbptr<float>(ld + 8); b.r = zbptr<float>(ld + 8); }
     bufs.push_back(b);
     return (int)bufs.size() - 1;
   }
@@ -315,7 +317,7 @@ struct Builder {
     b.rm = P.buffers + rm.off; b.rv = P.buffers + rv.off;
     const int cp = rup(C, 8) + 8;
     b.scale = wptr<float>(cp); b.shift = wptr<float>(cp); b.mean = wptr<float>(cp); b.invstd = wptr<float>(cp);
-    b.red1 = zptr<double>(cp); b.red2 = zptr<double>(cp);
+    b.red1 = zbptr<double>(cp); b.red2 = zbptr<double>(cp);
     bns.push_back(b);
     return (int)bns.size() - 1;
   }
@@ -356,7 +358,7 @@ struct Builder {
     for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
     const size_t elems = (size_t)chunks * pd.Npad * BK;
     pd.dst = wptr<uint8_t>(elems * esz);
-    if (!dgrad_seg) pd.dpack = zptr<float>(elems);
+    if (!dgrad_seg) pd.dpack = zbptr<float>(elems);
     if (!dgrad_seg && pd.gw) pd.gw += 0;
     P.packs.push_back(pd);
     return (int)P.packs.size() - 1;
@@ -873,7 +875,7 @@ struct Builder {
     pack_dev = wptr<PackDesc>(P.packs.size());
     prefix_dev = wptr<int>(P.packs.size());
     P.metrics_bytes = (size_t)(2 * g.nc + (size_t)d.batch * 2 * g.nc) * sizeof(double);
-    P.metrics = zptr<double>(P.metrics_bytes / sizeof(double));
+    P.metrics = zbptr<double>(P.metrics_bytes / sizeof(double));
 
     std::vector<Op> dummy;
     // ---- training forward ----
@@ -897,6 +899,7 @@ struct Builder {
     ops = sizing ? &dummy : &P.bwd;
     ops->clear();
     training = true;
+    { Op& o = push(OP_MEMSET); o.ms.p = zbbase; o.ms.bytes = 0; /* patched in plan_bind */ }
     {
       Op& o = push(OP_BCE);
       BceArgs& a = o.bce;
@@ -930,6 +933,7 @@ void plan_build_tables(dmm_plan* p) {
   b.build();
   b.emit_all();
   p->zero_bytes = (b.Z.off + 255) / 256 * 256;
+  p->zero_bwd_bytes = (b.ZB.off + 255) / 256 * 256;
   p->main_bytes = (b.W.off + 255) / 256 * 256;
   p->fwd_flops = b.flops;
   p->packs.clear();
@@ -944,9 +948,12 @@ void plan_bind(dmm_plan* p, void* ws) {
   // the training forward starts by zeroing the whole accumulator region
   p->fwd_train[0].ms.p = ws;
   p->fwd_train[0].ms.bytes = p->zero_bytes;
+  // ... and the backward by zeroing its own accumulators, so it can be repeated after one forward
+  p->bwd[0].ms.p = (uint8_t*)ws + p->zero_bytes;
+  p->bwd[0].ms.bytes = p->zero_bwd_bytes;
   p->ws = ws;
   // zero everything once: padding lanes of scale/shift tables and NHWC8 pad channels must read as 0
-  hipMemset(ws, 0, p->zero_bytes + p->main_bytes);
+  hipMemset(ws, 0, p->zero_bytes + p->zero_bwd_bytes + p->main_bytes);
   // upload the pack tables
   hipMemcpy(b.pack_dev, p->packs.data(), p->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   hipMemcpy(b.prefix_dev, p->pack_prefix.data(), p->pack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);

@@ -65,7 +65,7 @@ struct dmm_plan {
   dmm_model_desc desc;
   std::vector<dmm::TensorInfo> tensors;
   int64_t nparams = 0, nbuf = 0;
-  size_t zero_bytes = 0, main_bytes = 0;
+  size_t zero_bytes = 0, zero_bwd_bytes = 0, main_bytes = 0;
   double fwd_flops = 0;
   bool bound = false;
   void* ws = nullptr;

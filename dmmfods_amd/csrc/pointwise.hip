@@ -16,14 +16,14 @@ namespace dmm {
 template <typename T>
 __global__ __launch_bounds__(256) void convert_input_kernel(ConvertArgs a) {
   // one thread per pixel; reads are coalesced along x within each NCHW plane
-  __shared__ float red[16];
-  if (threadIdx.x < 16) red[threadIdx.x] = 0.f;
+  __shared__ double red[16];
+  if (threadIdx.x < 16) red[threadIdx.x] = 0.0;
   __syncthreads();
   const size_t plane = (size_t)a.H * a.W;
   const size_t npix = (size_t)a.B * plane;
-  float s1[8], s2[8];
+  double s1[8], s2[8];  // fp64 from the first add (see igemm.hip)
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  for (int c = 0; c < 8; ++c) { s1[c] = 0.0; s2[c] = 0.0; }
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
     const size_t b = p / plane, rem = p - b * plane;
     float v[8];
@@ -39,22 +39,22 @@ __global__ __launch_bounds__(256) void convert_input_kernel(ConvertArgs a) {
     for (int c = 0; c < 8; ++c) {
       const T t = from_f32<T>(v[c]);
       d[c] = t;
-      const float f = to_f32(t);
+      const double f = (double)to_f32(t);
       s1[c] += f;
-      s2[c] = fmaf(f, f, s2[c]);
+      s2[c] += f * f;
     }
   }
   if (a.stat_sum == nullptr) return;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    float x = s1[c], y = s2[c];
+    double x = s1[c], y = s2[c];
     for (int o = 32; o > 0; o >>= 1) { x += __shfl_down(x, o); y += __shfl_down(y, o); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&red[c], x); atomicAdd(&red[8 + c], y); }
   }
   __syncthreads();
   if (threadIdx.x < 8) {
-    atomic_add_f64(a.stat_sum + threadIdx.x, (double)red[threadIdx.x]);
-    atomic_add_f64(a.stat_sq + threadIdx.x, (double)red[8 + threadIdx.x]);
+    atomic_add_f64(a.stat_sum + threadIdx.x, red[threadIdx.x]);
+    atomic_add_f64(a.stat_sq + threadIdx.x, red[8 + threadIdx.x]);
   }
 }
 
@@ -123,9 +123,9 @@ hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 // Block-wide per-channel reduction helper: NCV slot columns x (256/NCV) row lanes.
 template <int SLOT>
-__device__ __forceinline__ void block_channel_reduce(float* red, int C, int cbase, const float (&s1)[SLOT],
-                                                     const float (&s2)[SLOT], double* d1, double* d2) {
-  // red: 2*C floats, zeroed and synchronised by the caller
+__device__ __forceinline__ void block_channel_reduce(double* red, int C, int cbase, const double (&s1)[SLOT],
+                                                     const double (&s2)[SLOT], double* d1, double* d2) {
+  // red: 2*C doubles, zeroed and synchronised by the caller
 #pragma unroll
   for (int i = 0; i < SLOT; ++i) {
     atomicAdd(&red[cbase + i], s1[i]);
@@ -133,8 +133,8 @@ __device__ __forceinline__ void block_channel_reduce(float* red, int C, int cbas
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomic_add_f64(d1 + c, (double)red[c]);
-    atomic_add_f64(d2 + c, (double)red[C + c]);
+    atomic_add_f64(d1 + c, red[c]);
+    atomic_add_f64(d2 + c, red[C + c]);
   }
 }
 
@@ -142,17 +142,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   typedef typename TT<T>::vec V;
-  extern __shared__ float red[];
-  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+  extern __shared__ double red[];
+  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.0;
   __syncthreads();
   const int ncv = a.C / SLOT;
   const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv, rpb = blockDim.x / ncv;
   const int c = cv * SLOT;
-  float sc[SLOT], sh[SLOT], s1[SLOT], s2[SLOT];
+  float sc[SLOT], sh[SLOT];
+  double s1[SLOT], s2[SLOT];
   load_f32s<SLOT>(a.scale + c, sc);
   load_f32s<SLOT>(a.shift + c, sh);
 #pragma unroll
-  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
   const int npix = a.B * a.Hp * a.Wp;
   const T* y0 = (const T*)a.y0;
   T* out = (T*)a.out;
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
         a.argmax[(size_t)p * a.C + c + i] = (unsigned char)arg[i];
-        s1[i] += r[i];
-        s2[i] = fmaf(r[i], r[i], s2[i]);
+        s1[i] += (double)r[i];
+        s2[i] += (double)r[i] * (double)r[i];
       }
     }
   }
@@ -196,7 +197,7 @@ hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st) {
   const int npix = a.B * a.Hp * a.Wp;
   int grid = (npix + rpb - 1) / rpb;
   if (grid > 8192) grid = 8192;
-  const size_t smem = 2 * a.C * sizeof(float);
+  const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
   return hipGetLastError();
@@ -208,19 +209,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   typedef typename TT<T>::vec V;
-  extern __shared__ float red[];
-  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+  extern __shared__ double red[];
+  for (int i = threadIdx.x; i < 2 * a.C; i += blockDim.x) red[i] = 0.0;
   __syncthreads();
   const int ncv = a.C / SLOT;
   const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv, rpb = blockDim.x / ncv;
   const int c = cv * SLOT;
-  float sc[SLOT], sh[SLOT], q[SLOT], rr[SLOT], s1[SLOT], s2[SLOT];
+  float sc[SLOT], sh[SLOT], q[SLOT], rr[SLOT];
+  double s1[SLOT], s2[SLOT];
   load_f32s<SLOT>(a.scale + c, sc);
   load_f32s<SLOT>(a.shift + c, sh);
   load_f32s<SLOT>(a.q + c, q);
   load_f32s<SLOT>(a.r + c, rr);
 #pragma unroll
-  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
   const int npix = a.B * a.H0 * a.W0;
   const T* y0 = (const T*)a.y0;
   const T* gp = (const T*)a.gpool;
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
         const float dz = (fmaf(yf[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
-        s1[i] += dz;
-        s2[i] = fmaf(dz, yf[i], s2[i]);
+        s1[i] += (double)dz;
+        s2[i] += (double)dz * (double)yf[i];
         o[i] = sc[i] * dz;
       }
       *(V*)(gy0 + (size_t)p * a.ld0 + c) = f32_to_vec<T>(o);
@@ -273,7 +275,7 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
   const int npix = a.B * a.H0 * a.W0;
   int grid = (npix + rpb - 1) / rpb;
   if (grid > 8192) grid = 8192;
-  const size_t smem = 2 * a.C * sizeof(float);
+  const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
   return hipGetLastError();

@@ -189,12 +189,30 @@ def test_c1_densenet121_golden_and_directional_derivative(golden_dir):
     got = logits.flatten()[:: int(mom[1])][: len(sample)].cpu()
     assert ((got - sample).abs().max() / mom[4]).item() < 1e-3
     np.testing.assert_allclose(met["loss_per_class"].cpu().double().numpy(), g["loss_per_class"], rtol=1e-4)
+    # Gradients.  On this network the reference's own fp32 arithmetic is only good to ~1e-2 of a tensor's absmax
+    # (median over tensors; up to 0.18) against an fp64 run -- measured with the CPU oracle -- so: (i) the sampled
+    # gradients in the reference-generated fixture are matched at 3e-2, (ii) every tensor is compared with the fp64
+    # oracle using the CPU-fp32 oracle's own error as yardstick, (iii) the global relative L2 error must not exceed
+    # 3x that of CPU fp32.
     for k in ("features.conv0.weight", "features.denseblock3.denselayer24.conv2.weight", "decoder.Transposed_Convolution_2.weight",
               "dec_out_to_heat_maps.refine1.weight"):
         mom, sample = g[f"grad/{k}/mom"], torch.from_numpy(g[f"grad/{k}/sample"])
         p = dict(model.named_parameters())[k]
         got = p.grad.flatten()[:: int(mom[1])][: len(sample)].cpu()
-        assert ((got - sample).abs().max() / mom[4]).item() < 5e-3, k
+        assert ((got - sample).abs().max() / mom[4]).item() < 3e-2, k
+    _, g64, _, _ = _oracle_step(R, arch, torch.float64, B=1, H=256, W=384)
+    _, g32, _, _ = _oracle_step(R, arch, torch.float32, B=1, H=256, W=384)
+    num = den = num32 = 0.0
+    for k, p in model.named_parameters():
+        ref = g64[k]
+        s = ref.abs().max().clamp_min(1e-30)
+        err = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
+        noise = ((g32[k].double() - ref).abs().max() / s).item()
+        assert err < max(3e-3, 4 * noise), (k, err, noise)
+        num += (p.grad.detach().cpu().double() - ref).pow(2).sum().item()
+        num32 += (g32[k].double() - ref).pow(2).sum().item()
+        den += ref.pow(2).sum().item()
+    assert (num / den) ** 0.5 < max(1e-3, 3 * (num32 / den) ** 0.5), ((num / den) ** 0.5, (num32 / den) ** 0.5)
     # directional derivative along a random direction (fp32 forward noise limits eps from below)
     grad = model.grad_arena.clone()
     gen = torch.Generator(device=DEV).manual_seed(1)
