@@ -41,8 +41,10 @@ struct Seg {
   const void* src2;    // companion tensor for the effective-gradient prologue (nullable)
   const float* scale;  // BN+ReLU prologue: v = max(v*scale[c] + shift[c], 0)   (nullable)
   const float* shift;
-  const float* q;      // effective gradient: v = src + q[c] + r[c]*src2         (nullable)
-  const float* r;
+  const float* q;      // effective gradient: v = src + (q+ql)[c] + (r+rl)[c]*src2  (nullable); the per-channel
+  const float* r;      // constants are fp64 values split into float hi (q, r) and lo (ql, rl) parts
+  const float* ql;
+  const float* rl;
   int ld, ld2;
   int Hs, Ws;   // source spatial size
   int C;        // real channels (multiple of SLOT)

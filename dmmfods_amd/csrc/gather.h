@@ -107,13 +107,15 @@ __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b,
   }
   if (sg.q != nullptr) {
     V v2 = *(const V*)((const T*)sg.src2 + pix * sg.ld2 + c);
-    float f[S], f2[S], q[S], r[S];
+    float f[S], f2[S], q[S], r[S], ql[S], rl[S];
     vec_to_f32<T>(v, f);
     vec_to_f32<T>(v2, f2);
     load_f32s<S>(sg.q + c, q);
     load_f32s<S>(sg.r + c, r);
+    load_f32s<S>(sg.ql + c, ql);
+    load_f32s<S>(sg.rl + c, rl);
 #pragma unroll
-    for (int i = 0; i < S; ++i) f[i] = f[i] + fmaf(r[i], f2[i], q[i]);
+    for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(r[i], f2[i], q[i])) + fmaf(rl[i], f2[i], ql[i]);
     return f32_to_vec<T>(f);
   }
   return v;

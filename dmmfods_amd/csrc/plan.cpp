@@ -218,8 +218,12 @@ struct Buf {
   uint8_t* g = nullptr;   // raw gradient (T), same layout
   double* ssum = nullptr; // per-channel sum / sum^2 of x
   double* ssq = nullptr;
-  float* q = nullptr;     // deferred BN-backward correction of g
+  float* q = nullptr;     // deferred BN-backward correction of g: float hi parts ...
   float* r = nullptr;
+  float* ql = nullptr;    // ... lo parts ...
+  float* rl = nullptr;
+  double* qd = nullptr;   // ... and the fp64 accumulators they are split from
+  double* rd = nullptr;
   bool ginit = false;
 };
 
@@ -302,7 +306,10 @@ struct Builder {
     b.x = wptr<uint8_t>(n * esz);
     if (grad) b.g = wptr<uint8_t>(n * esz);
     if (stats) { b.ssum = zptr<double>(ld); b.ssq = zptr<double>(ld); }
-    if (grad) { b.q = zbptr<float>(ld + 8); b.r = zbptr<float>(ld + 8); }
+    if (grad) {
+      b.q = zbptr<float>(ld + 8); b.r = zbptr<float>(ld + 8); b.ql = zbptr<float>(ld + 8); b.rl = zbptr<float>(ld + 8);
+      b.qd = zbptr<double>(ld + 8); b.rd = zbptr<double>(ld + 8);
+    }
     bufs.push_back(b);
     return (int)bufs.size() - 1;
   }
@@ -488,7 +495,7 @@ struct Builder {
     s.C = C; s.Cpad = C;
     s.mode = G_PLAIN;
     s.istride = istride;
-    if (b.q) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; }
+    if (b.q) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; s.ql = b.ql + ch0; s.rl = b.rl + ch0; }
     fill_seg_taps(s, taps, BK);
   }
 
@@ -501,8 +508,10 @@ struct Builder {
       a.mean = b.mean + rg.c0; a.invstd = b.invstd + rg.c0; a.scale = b.scale + rg.c0;
       a.dgamma = b.dgamma + rg.c0; a.dbeta = b.dbeta + rg.c0;
       const Buf& sb = bufs[rg.buf];
-      a.q = (rg.want_qr && sb.q) ? sb.q + rg.ch0 : nullptr;
-      a.r = (rg.want_qr && sb.r) ? sb.r + rg.ch0 : nullptr;
+      const bool qr = rg.want_qr && sb.q;
+      a.qd = qr ? sb.qd + rg.ch0 : nullptr; a.rd = qr ? sb.rd + rg.ch0 : nullptr;
+      a.q = qr ? sb.q + rg.ch0 : nullptr; a.r = qr ? sb.r + rg.ch0 : nullptr;
+      a.ql = qr ? sb.ql + rg.ch0 : nullptr; a.rl = qr ? sb.rl + rg.ch0 : nullptr;
       a.count = rg.count;
       a.grad_scale = 1.0f / d.loss_scale;
       a.C = rg.n;
@@ -522,7 +531,10 @@ struct Builder {
       a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
       a.dy.src = gat(c.obuf, c.och0);
       a.dy.ld = ob.ld;
-      if (ob.q) { a.dy.src2 = xat(c.obuf, c.och0); a.dy.ld2 = ob.ld; a.dy.q = ob.q + c.och0; a.dy.r = ob.r + c.och0; }
+      if (ob.q) {
+        a.dy.src2 = xat(c.obuf, c.och0); a.dy.ld2 = ob.ld;
+        a.dy.q = ob.q + c.och0; a.dy.r = ob.r + c.och0; a.dy.ql = ob.ql + c.och0; a.dy.rl = ob.rl + c.och0;
+      }
       const PackDesc& pd = P.packs[ph.pack];
       a.N = c.N; a.Npad = pd.Npad;
       a.Hout = ob.H; a.Wout = ob.W; a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
@@ -606,7 +618,7 @@ struct Builder {
     a.y0 = yb.x; a.ld0 = yb.ld; a.H0 = yb.H; a.W0 = yb.W; a.B = yb.B; a.C = p.C;
     a.scale = bns[p.bn].scale; a.shift = bns[p.bn].shift;
     a.gpool = gat(p.obuf, p.och0); a.xpool = xat(p.obuf, p.och0);
-    a.q = ob.q + p.och0; a.r = ob.r + p.och0;
+    a.q = ob.q + p.och0; a.r = ob.r + p.och0; a.ql = ob.ql + p.och0; a.rl = ob.rl + p.och0;
     a.ldg = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
     a.argmax = p.argmax;
     a.gy0 = yb.g;

@@ -41,8 +41,12 @@ struct BnBwdFinalizeArgs {
   const float* scale;
   float* dgamma;
   float* dbeta;
-  float* q;  // deferred correction accumulators of the normalised tensor (nullable)
+  double* qd;  // deferred correction accumulators of the normalised tensor, fp64 (nullable)
+  double* rd;
+  float* q;    // float hi / lo split of the accumulators, rewritten after every update
   float* r;
+  float* ql;
+  float* rl;
   double count;      // positions of the normalised tensor
   float grad_scale;  // 1 / loss_scale
   int C;
@@ -69,6 +73,8 @@ struct MaxpoolBwdArgs {
   const void* xpool;  // pooled forward tensor (same layout) for the deferred correction
   const float* q;
   const float* r;
+  const float* ql;
+  const float* rl;
   int ldg, Hp, Wp;
   const unsigned char* argmax;
   void* gy0;  // (B, H0, W0, ld0): s * dz0

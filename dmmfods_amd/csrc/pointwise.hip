@@ -106,12 +106,19 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   const double dotp = (S2 - mu * S1) * is;  // sum dz * xhat
   a.dgamma[c] = (float)(dotp * a.grad_scale);
   a.dbeta[c] = (float)(S1 * a.grad_scale);
-  if (a.q != nullptr) {
+  if (a.qd != nullptr) {
     const double s = a.scale[c];
     const double c1 = S1 / a.count, c2 = dotp / a.count;
-    // contribution of this consumer to d/dx:  s*dz (stored by the dgrad epilogue)  - s*c1 - s*c2*(x-mu)*is
-    a.q[c] += (float)(-s * c1 + s * c2 * mu * is);
-    a.r[c] += (float)(-s * c2 * is);
+    // contribution of this consumer to d/dx:  s*dz (stored by the dgrad epilogue)  - s*c1 - s*c2*(x-mu)*is.
+    // Accumulated in fp64 over all consumers of the channel (they cancel heavily inside dense blocks) and handed to
+    // the gathers as a two-float split: a rounding error here would be a coherent per-channel gradient offset.
+    const double q = a.qd[c] + (-s * c1 + s * c2 * mu * is);
+    const double r = a.rd[c] + (-s * c2 * is);
+    a.qd[c] = q;
+    a.rd[c] = r;
+    const float qh = (float)q, rh = (float)r;
+    a.q[c] = qh; a.ql[c] = (float)(q - (double)qh);
+    a.r[c] = rh; a.rl[c] = (float)(r - (double)rh);
   }
 }
 
@@ -215,12 +222,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
   const int ncv = a.C / SLOT;
   const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv, rpb = blockDim.x / ncv;
   const int c = cv * SLOT;
-  float sc[SLOT], sh[SLOT], q[SLOT], rr[SLOT];
+  float sc[SLOT], sh[SLOT], q[SLOT], rr[SLOT], qlo[SLOT], rlo[SLOT];
   double s1[SLOT], s2[SLOT];
   load_f32s<SLOT>(a.scale + c, sc);
   load_f32s<SLOT>(a.shift + c, sh);
   load_f32s<SLOT>(a.q + c, q);
   load_f32s<SLOT>(a.r + c, rr);
+  load_f32s<SLOT>(a.ql + c, qlo);
+  load_f32s<SLOT>(a.rl + c, rlo);
 #pragma unroll
   for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
   const int npix = a.B * a.H0 * a.W0;
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
           vec_to_f32<T>(*(const V*)(xp + op * a.ldg + c), xf);
 #pragma unroll
           for (int i = 0; i < SLOT; ++i)
-            if (a.argmax[op * a.C + c + i] == k) g[i] += gf[i] + fmaf(rr[i], xf[i], q[i]);
+            if (a.argmax[op * a.C + c + i] == k) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
         }
       }
       float yf[SLOT], o[SLOT];

@@ -124,13 +124,15 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
           v = *(const V*)p;
           if (a.dy.q != nullptr) {
             const V y2 = *(const V*)((const T*)a.dy.src2 + (size_t)e.w * a.dy.ld2 + nD);
-            float f[SLOT], f2[SLOT], q[SLOT], r[SLOT];
+            float f[SLOT], f2[SLOT], q[SLOT], r[SLOT], ql[SLOT], rl[SLOT];
             vec_to_f32<T>(v, f);
             vec_to_f32<T>(y2, f2);
             load_f32s<SLOT>(a.dy.q + nD, q);
             load_f32s<SLOT>(a.dy.r + nD, r);
+            load_f32s<SLOT>(a.dy.ql + nD, ql);
+            load_f32s<SLOT>(a.dy.rl + nD, rl);
 #pragma unroll
-            for (int u = 0; u < SLOT; ++u) f[u] = f[u] + fmaf(r[u], f2[u], q[u]);
+            for (int u = 0; u < SLOT; ++u) f[u] = (f[u] + fmaf(r[u], f2[u], q[u])) + fmaf(rl[u], f2[u], ql[u]);
             v = f32_to_vec<T>(f);
           }
         }

@@ -202,17 +202,25 @@ def test_c1_densenet121_golden_and_directional_derivative(golden_dir):
         assert ((got - sample).abs().max() / mom[4]).item() < 3e-2, k
     _, g64, _, _ = _oracle_step(R, arch, torch.float64, B=1, H=256, W=384)
     _, g32, _, _ = _oracle_step(R, arch, torch.float32, B=1, H=256, W=384)
+    # The noise is heavy-tailed (measured: per-tensor max-error ratios GPU/CPU-fp32 spread 0.1x .. 8x with median 1.1
+    # and equal global L2), so the per-tensor bounds are norm-wise with a loose max-norm backstop.
     num = den = num32 = 0.0
+    ratios = []
     for k, p in model.named_parameters():
         ref = g64[k]
+        d = p.grad.detach().cpu().double() - ref
+        d32 = g32[k].double() - ref
         s = ref.abs().max().clamp_min(1e-30)
-        err = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
-        noise = ((g32[k].double() - ref).abs().max() / s).item()
-        assert err < max(3e-3, 4 * noise), (k, err, noise)
-        num += (p.grad.detach().cpu().double() - ref).pow(2).sum().item()
-        num32 += (g32[k].double() - ref).pow(2).sum().item()
+        err, noise = (d.abs().max() / s).item(), (d32.abs().max() / s).item()
+        assert err < max(3e-3, 12 * noise), (k, err, noise)
+        rn = ref.norm().clamp_min(1e-30)
+        assert (d.norm() / rn).item() < max(2e-3, 8 * (d32.norm() / rn).item()), (k, (d.norm() / rn).item(), (d32.norm() / rn).item())
+        ratios.append(err / max(noise, 1e-12))
+        num += d.pow(2).sum().item()
+        num32 += d32.pow(2).sum().item()
         den += ref.pow(2).sum().item()
-    assert (num / den) ** 0.5 < max(1e-3, 3 * (num32 / den) ** 0.5), ((num / den) ** 0.5, (num32 / den) ** 0.5)
+    assert float(np.median(ratios)) < 2.0, float(np.median(ratios))
+    assert (num / den) ** 0.5 < max(1e-3, 2 * (num32 / den) ** 0.5), ((num / den) ** 0.5, (num32 / den) ** 0.5)
     # directional derivative along a random direction (fp32 forward noise limits eps from below)
     grad = model.grad_arena.clone()
     gen = torch.Generator(device=DEV).manual_seed(1)
