@@ -117,16 +117,23 @@ def roofline_block(classes, dtype):
 def cpu_baseline(max_seconds=25.0):
     """The CPU oracle (oracle/restatement.py, kind 'port') timed on this host: BASELINE.json configs[0] (C1)."""
     from oracle import restatement as R
-    ncores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # the GPU box grants a 16-core share per GPU whatever os.cpu_count() says; oversubscribing makes torch crawl
+    ncores = max(1, min(avail, int(os.environ.get("DMM_CPU_THREADS", "16"))))
     torch.set_num_threads(ncores)
+    print(f"[bench] cpu_baseline: oracle on {ncores} threads ...", file=sys.stderr, flush=True)
     arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=0)
     P = R.make_state(arch, seed=123)
     tr = R.Trainer(arch, P)
     rgb, lidar, tgt = R.make_inputs(arch, 1, 256, 384, seed=0)
-    tr.step(rgb, lidar, tgt)  # warm-up
-    times = []
     t_start = time.time()
-    while len(times) < 5 and time.time() - t_start < max_seconds:
+    tr.step(rgb, lidar, tgt)  # warm-up
+    print(f"[bench] cpu_baseline: warm-up step {time.time() - t_start:.2f} s", file=sys.stderr, flush=True)
+    times = []
+    while len(times) < 5 and (not times or time.time() - t_start < max_seconds):
         t0 = time.time()
         tr.step(rgb, lidar, tgt)
         times.append(time.time() - t0)
