@@ -55,7 +55,7 @@ def synthetic_batch(c, device, seed):
     return rgb, lidar, tgt
 
 
-def collect_profile(model, plan, K):
+def collect_profile(model, plan, K, ops_out=None):
     from dmmfods_amd import _lib
     L = _lib.lib()
     classes = {}
@@ -70,6 +70,8 @@ def collect_profile(model, plan, K):
             label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
             L.dmm_plan_profile_op(plan.handle, which, i, C.byref(label), C.byref(fl), C.byref(by))
             cls = (label.value or b"").decode().split("/")[0] or "other"
+            if ops_out is not None and ms[i] > 0:
+                ops_out.append((ms[i] / passes.value, (label.value or b"").decode(), fl.value, by.value))
             e = classes.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             e["ms"] += ms[i]
             e["launches"] += passes.value
@@ -154,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--table", action="store_true", help="also print the per-kernel-class table to stderr")
+    ap.add_argument("--ops", type=int, default=0, help="print the N most expensive launches (per step) to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,7 +221,12 @@ def main():
         value = c["batch"] * world * args.steps / elapsed
         roof, table = (None, None)
         if not args.no_profile:
-            roof, table = roofline_block(collect_profile(model, plan, args.steps), c["dtype"])
+            ops_list = [] if args.ops else None
+            roof, table = roofline_block(collect_profile(model, plan, args.steps, ops_list), c["dtype"])
+            if ops_list:
+                ops_list.sort(reverse=True)
+                for ms_, lab, fl, by in ops_list[:args.ops]:
+                    print(f"{ms_:9.3f} ms  {lab:48s} {fl / ms_ / 1e9 if ms_ else 0:8.1f} TF/s {by / ms_ / 1e6 if ms_ else 0:8.1f} GB/s", file=sys.stderr)
         fwd_flops_img = plan.flops_forward / c["batch"]
         out = {
             "metric": "training images/sec at 1280x1920 RGB+LiDAR",

@@ -387,9 +387,10 @@ int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const 
     a.nseg = 1;
     fill_one_seg(a.seg[0], d, g, x, scale, shift, g.phase_taps[ph]);
     a.B = d->B; a.Ho = g.Ho; a.Wo = g.Wo; a.M = d->B * g.Ho * g.Wo;
-    a.dy.src = dy; a.dy.ld = d->Cout;
+    a.dy.src = dy; a.dy.ld = d->Cout; a.dy.Hs = g.Hout; a.dy.Ws = g.Wout; a.dy.C = rup(d->Cout, 8); a.dy.Cpad = a.dy.C;
+    a.dy.mode = G_PLAIN; a.dy.istride = g.ostride; a.dy.ntaps = 1; a.dy.nchunks = 1;
+    a.dy.taps[0] = (short)((g.phase_xy[ph].first & 0xff) | ((g.phase_xy[ph].second & 0xff) << 8));
     a.N = d->Cout; a.Npad = packs[ph].Npad;
-    a.Hout = g.Hout; a.Wout = g.Wout; a.ostride = g.ostride; a.py = g.phase_xy[ph].first; a.px = g.phase_xy[ph].second;
     a.dpack = (float*)packs[ph].dpack;
     HIPCHK(launch_wgrad(a, d->dtype, d->use_mfma != 0, st));
   }

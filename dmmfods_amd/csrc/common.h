@@ -86,9 +86,8 @@ struct WgradArgs {
   Seg seg[2];
   int nseg;
   int B, Ho, Wo, M;
-  Seg dy;        // the dY operand: uses src/src2/q/r/ld/ld2 and C = N; pixel mapping below
+  Seg dy;        // the pixel-aligned operand P: a one-tap Seg (tap = (py,px), istride = ostride for ConvTranspose phases)
   int N, Npad;
-  int Hout, Wout, ostride, py, px, coff;
   float* dpack;  // fp32 packed gradient [chunk][Npad][BK]
   int rows_per_split;  // multiple of BM
   int kgroups;         // number of K groups (each WG_CHUNKS chunks)

@@ -256,6 +256,7 @@ struct ConvRec {
   bool stats;
   std::vector<PhaseRec> phases;
   int dpack[2];
+  bool wgrad_transposed;  // taps on the gradient side (see wgrad.hip)
 };
 struct PoolRec { int y0buf, bn, obuf, och0; uint8_t* argmax; int C; };
 struct Rec { int type; int idx; };  // 0 conv, 1 pool
@@ -522,6 +523,25 @@ struct Builder {
     const Buf& ob = bufs[c.obuf];
     const int Nst = rup(c.N, 8);  // storage channels of the output gradient
     // ---- weight gradient, one launch per phase ----
+    auto one_tap_seg = [&](Seg& s, int py, int px) {
+      s.ntaps = 1; s.nchunks = 1;
+      s.taps[0] = (short)((py & 0xff) | ((px & 0xff) << 8));
+    };
+    if (c.wgrad_transposed) {
+      Op& o = push(OP_WGRAD);
+      WgradArgs& a = o.w;
+      memset(&a, 0, sizeof(a));
+      a.nseg = 1;
+      fill_grad_seg(a.seg[0], c.obuf, c.och0, Nst, taps_conv_dgrad(c.R, c.S, c.pad), 1);   // Q: dY with flipped taps
+      a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
+      fill_fwd_seg(a.dy, c.seg[0], taps_conv(1, 1, 0));                                      // P: activated input, once
+      const PackDesc& pd = P.packs[c.dpack[0]];
+      a.N = c.seg[0].C; a.Npad = pd.Npad;
+      a.dpack = (float*)pd.dpack;
+      char cb[32];
+      tag(o, ncls("wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
+          src_bytes(c) + (ob.q ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
+    } else
     for (auto& ph : c.phases) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;
@@ -529,15 +549,10 @@ struct Builder {
       a.nseg = c.nseg;
       for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], ph.taps);
       a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
-      a.dy.src = gat(c.obuf, c.och0);
-      a.dy.ld = ob.ld;
-      if (ob.q) {
-        a.dy.src2 = xat(c.obuf, c.och0); a.dy.ld2 = ob.ld;
-        a.dy.q = ob.q + c.och0; a.dy.r = ob.r + c.och0; a.dy.ql = ob.ql + c.och0; a.dy.rl = ob.rl + c.och0;
-      }
+      fill_grad_seg(a.dy, c.obuf, c.och0, Nst, taps_conv(1, 1, 0), c.ostride);
+      one_tap_seg(a.dy, ph.py, ph.px);
       const PackDesc& pd = P.packs[ph.pack];
       a.N = c.N; a.Npad = pd.Npad;
-      a.Hout = ob.H; a.Wout = ob.W; a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
       a.dpack = (float*)pd.dpack;
       {
         char cb[32];
@@ -634,6 +649,7 @@ struct Builder {
     c.wname = wname; c.transposed = transposed; c.N = N; c.Kin = Kin; c.R = R; c.S = S; c.pad = pad;
     c.nseg = 1; c.ostride = 1; c.epi = EPI_STORE; c.stats = true;
     c.dpack[0] = c.dpack[1] = -1;
+    c.wgrad_transposed = false;
     memset(c.seg, 0, sizeof(c.seg));
     c.seg[0].bn = c.seg[1].bn = -1;
     convs.push_back(c);
@@ -653,6 +669,17 @@ struct Builder {
         default: continue;
       }
       c.dpack[s] = add_pack(c, t, true, s);
+    }
+    // thin outputs: compute the weight gradient in the transposed form; it fills the dgrad-shaped packed gradient
+    if (c.nseg == 1 && !c.transposed && c.seg[0].mode == G_PLAIN && c.seg[0].istride == 1 && c.seg[0].dgrad == DG_FLIP &&
+        c.R * c.S > 1 && rup(c.N, 8) < c.seg[0].C && c.phases.size() == 1) {
+      c.wgrad_transposed = true;
+      PackDesc& dp = P.packs[c.dpack[0]];
+      int chunks = 0;
+      for (int s2 = 0; s2 < dp.nseg; ++s2) chunks += dp.seg[s2].nchunks;
+      dp.dpack = zbptr<float>((size_t)chunks * dp.Npad * BK);
+      dp.gw = P.grads + (dp.w - P.params);
+      P.packs[c.phases[0].pack].gw = nullptr;  // the forward-shaped packed gradient is not produced
     }
     // FLOPs (2*MACs) in the reference's formulation
     const double px = (double)c.B * c.Ho * c.Wo * (c.seg[0].mode == G_POOL2 ? 4.0 : 1.0);

@@ -1,6 +1,11 @@
-// Weight-gradient GEMM for gfx950:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k]
-//   A    = exactly the gathered operand of the forward implicit GEMM (same taps, BN+ReLU prologue, modes)
-//   dYeff= output gradient with the deferred BatchNorm-backward correction  g + q[n] + r[n]*y  applied on load
+// Weight-gradient GEMM for gfx950:  dP[chunk][n][k] += sum_m P[m][n] * Q[m][k]
+//   Both operands come through gather_slot (gather.h): P is pixel-aligned (one tap), Q carries the taps.
+//   standard form   : P = dYeff (output gradient + deferred BatchNorm-backward correction), Q = the forward conv's
+//                     gathered operand A (same taps, BN+ReLU prologue, modes); dP is laid out like the forward pack.
+//   transposed form : P = A at the pixel (BN+ReLU applied ONCE per pixel), Q = dYeff gathered with the flipped taps,
+//                     dW[n][c][tap] = sum_m' dY[m'-tap][n] * A[m'][c]; dP is laid out like the dgrad pack.  Chosen by the
+//                     plan when the output is thin (N*taps < Cin*taps), e.g. the 3x3 growth convs (N = 32) and the
+//                     5x5 logits conv (N = 3): the per-tap prologue work moves from Cin to N channels.
 //   dP   = gradient w.r.t. the PACKED weights (fp32, layout [chunk][Npad][BK]); unpack_grads scatters it back.
 // The contraction index is the pixel m, which is the slow (strided) index of both NHWC operands, so both MFMA
 // operands are read from row-major LDS tiles with the hardware transposing read ds_read_b64_tr_b16 (16-bit
@@ -30,7 +35,7 @@ struct WgradSmem {
   static constexpr int PA = pitch_for(KW * (int)sizeof(T));
   static constexpr int D_BYTES = BMW * PD;
   static constexpr int A_BYTES = BMW * PA;
-  static constexpr int TAB = 2 * BMW * 16;  // two row tables of int4 {b, y, x, outpix}
+  static constexpr int TAB = 2 * BMW * 16;  // two row tables of int4 {b, y, x, valid}
   static constexpr int bytes = D_BYTES + A_BYTES + TAB;
 };
 
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
       int4 e;
       if (m < mend) {
         row_to_byx(m, a.Ho, a.Wo, e.x, e.y, e.z);
-        e.w = (e.x * a.Hout + e.y * a.ostride + a.py) * a.Wout + e.z * a.ostride + a.px;
+        e.w = 1;
       } else {
         e.x = e.y = e.z = 0;
         e.w = -1;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int4 e = rowtab[which * BMW + rga + i * RGA];
-      areg[i] = gather_slot<T>(sg, e.x, e.y, e.z, e.w >= 0, ktap, kc);
+      areg[i] = gather_slot<T>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc);
     }
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
@@ -119,23 +124,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
       for (int u = 0; u < SLOT; ++u) v[u] = (T)0;
       if (row < BMW) {
         const int4 e = rowtab[which * BMW + row];
-        if (e.w >= 0 && nD < a.N) {
-          const T* p = (const T*)a.dy.src + (size_t)e.w * a.dy.ld + nD;
-          v = *(const V*)p;
-          if (a.dy.q != nullptr) {
-            const V y2 = *(const V*)((const T*)a.dy.src2 + (size_t)e.w * a.dy.ld2 + nD);
-            float f[SLOT], f2[SLOT], q[SLOT], r[SLOT], ql[SLOT], rl[SLOT];
-            vec_to_f32<T>(v, f);
-            vec_to_f32<T>(y2, f2);
-            load_f32s<SLOT>(a.dy.q + nD, q);
-            load_f32s<SLOT>(a.dy.r + nD, r);
-            load_f32s<SLOT>(a.dy.ql + nD, ql);
-            load_f32s<SLOT>(a.dy.rl + nD, rl);
-#pragma unroll
-            for (int u = 0; u < SLOT; ++u) f[u] = (f[u] + fmaf(r[u], f2[u], q[u])) + fmaf(rl[u], f2[u], ql[u]);
-            v = f32_to_vec<T>(f);
-          }
-        }
+        if (nD < a.N) v = gather_slot<T>(a.dy, e.x, e.y, e.z, e.w > 0, 0, nD);
       }
       dreg[i] = v;
     }
