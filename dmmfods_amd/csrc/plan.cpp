@@ -73,6 +73,35 @@ std::vector<Tap> taps_up2_merged_dgrad() {
   return t;
 }
 
+// Forward 3x3 (pad 1) conv over a nearest-x2 upsampled source, restricted to output pixels (2y+e, 2x+f): the source row of
+// tap ky is y + floor((e + ky - 1) / 2), so e = 0 collects {ky=0} at -1 and {1,2} at 0; e = 1 collects {0,1} at 0 and {2} at +1.
+std::vector<Tap> taps_up2_phase(int e, int f) {
+  struct G { int off; int k[2]; };
+  static const G rows[2][2] = {{{-1, {0, -1}}, {0, {1, 2}}}, {{0, {0, 1}}, {1, {2, -1}}}};
+  std::vector<Tap> t;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const G &gy = rows[e][a], &gx = rows[f][b];
+      unsigned w = 0;
+      int cnt = 0;
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+          if (gy.k[i] < 0 || gx.k[j] < 0) continue;
+          w |= (unsigned)(gy.k[i] * 3 + gx.k[j]) << (8 * cnt++);
+        }
+      for (; cnt < 4; ++cnt) w |= 0xffu << (8 * cnt);
+      t.push_back({gy.off, gx.off, w});
+    }
+  return t;
+}
+// The same output pixels read a full-resolution source at (2y + e + ky - 1, 2x + f + kx - 1): stride-2 rows, taps offset by (e,f).
+std::vector<Tap> taps_conv_phase_s2(int e, int f) {
+  std::vector<Tap> t;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) t.push_back({e + ky - 1, f + kx - 1, tw1(ky * 3 + kx)});
+  return t;
+}
+
 void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK) {
   if ((int)taps.size() > MAX_TAPS) throw std::runtime_error("too many taps");
   s.ntaps = (int)taps.size();
@@ -243,7 +272,7 @@ struct SegRec {
   int bn, bn_c0;
   int dgrad;
 };
-struct PhaseRec { int py, px; std::vector<Tap> taps; int pack; };
+struct PhaseRec { int py, px; std::vector<Tap> taps; int pack; std::vector<Tap> taps1; /* segment 1, if different */ };
 struct ConvRec {
   std::string wname;
   bool transposed;
@@ -257,6 +286,8 @@ struct ConvRec {
   std::vector<PhaseRec> phases;
   int dpack[2];
   bool wgrad_transposed;  // taps on the gradient side (see wgrad.hip)
+  bool shared_master;     // several phases' packed gradients add into the same master weights
+  double flops_ref;       // 2*MACs in the reference's formulation when it differs from the launched geometry (else 0)
 };
 struct PoolRec { int y0buf, bn, obuf, och0; uint8_t* argmax; int C; };
 struct Rec { int type; int idx; };  // 0 conv, 1 pool
@@ -336,7 +367,7 @@ struct Builder {
   }
 
   // -------------------------------------------------------------------------------- pack registry
-  int add_pack(const ConvRec& c, const std::vector<Tap>& taps, bool dgrad_seg, int seg_index) {
+  int add_pack(const ConvRec& c, const std::vector<Tap>& taps, bool dgrad_seg, int seg_index, const std::vector<Tap>* taps1 = nullptr) {
     PackDesc pd;
     memset(&pd, 0, sizeof(pd));
     const TensorInfo& w = T(c.wname);
@@ -348,8 +379,10 @@ struct Builder {
       pd.nseg = c.nseg;
       if (!c.transposed) { pd.sn = c.Kin * RS; pd.sk = RS; }
       else { pd.sn = RS; pd.sk = (long long)c.N * RS; }
-      for (int s = 0; s < c.nseg; ++s) fill_pack_seg(pd.seg[s], taps, c.seg[s].Cw, c.seg[s].C, c.seg[s].koff, BK);
+      for (int s = 0; s < c.nseg; ++s)
+        fill_pack_seg(pd.seg[s], (s == 1 && taps1 && !taps1->empty()) ? *taps1 : taps, c.seg[s].Cw, c.seg[s].C, c.seg[s].koff, BK);
       pd.gw = P.grads + w.off;
+      pd.shared_master = c.shared_master ? 1 : 0;
     } else {
       const SegRec& sr = c.seg[seg_index];
       pd.N = sr.Cw;
@@ -398,6 +431,7 @@ struct Builder {
     return s;
   }
   double conv_flops(const ConvRec& c, size_t nphases) const {
+    if (c.flops_ref > 0) return c.flops_ref / (double)nphases;
     const double px = (double)c.B * c.Ho * c.Wo * (c.seg[0].mode == G_POOL2 ? 4.0 : 1.0);
     const double f = c.transposed ? 2.0 * px * c.N * c.Kin * 9.0 : 2.0 * px * c.N * c.Kin * c.R * c.S;
     return f / (double)nphases;
@@ -466,7 +500,7 @@ struct Builder {
       ConvArgs& a = o.c;
       memset(&a, 0, sizeof(a));
       a.nseg = c.nseg;
-      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], ph.taps);
+      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], (s == 1 && !ph.taps1.empty()) ? ph.taps1 : ph.taps);
       a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
       const PackDesc& pd = P.packs[ph.pack];
       a.wpack = pd.dst;
@@ -547,7 +581,7 @@ struct Builder {
       WgradArgs& a = o.w;
       memset(&a, 0, sizeof(a));
       a.nseg = c.nseg;
-      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], ph.taps);
+      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], (s == 1 && !ph.taps1.empty()) ? ph.taps1 : ph.taps);
       a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
       fill_grad_seg(a.dy, c.obuf, c.och0, Nst, taps_conv(1, 1, 0), c.ostride);
       one_tap_seg(a.dy, ph.py, ph.px);
@@ -650,6 +684,8 @@ struct Builder {
     c.nseg = 1; c.ostride = 1; c.epi = EPI_STORE; c.stats = true;
     c.dpack[0] = c.dpack[1] = -1;
     c.wgrad_transposed = false;
+    c.shared_master = false;
+    c.flops_ref = 0;
     memset(c.seg, 0, sizeof(c.seg));
     c.seg[0].bn = c.seg[1].bn = -1;
     convs.push_back(c);
@@ -658,7 +694,7 @@ struct Builder {
   }
   void finish_conv(ConvRec& c) {
     // forward packs (one per phase) and dgrad packs (one per segment that needs a data gradient)
-    for (auto& ph : c.phases) ph.pack = add_pack(c, ph.taps, false, 0);
+    for (auto& ph : c.phases) ph.pack = add_pack(c, ph.taps, false, 0, &ph.taps1);
     for (int s = 0; s < c.nseg; ++s) {
       std::vector<Tap> t;
       switch (c.seg[s].dgrad) {
@@ -682,9 +718,7 @@ struct Builder {
       P.packs[c.phases[0].pack].gw = nullptr;  // the forward-shaped packed gradient is not produced
     }
     // FLOPs (2*MACs) in the reference's formulation
-    const double px = (double)c.B * c.Ho * c.Wo * (c.seg[0].mode == G_POOL2 ? 4.0 : 1.0);
-    if (c.transposed) flops += 2.0 * px * c.N * c.Kin * 9.0;
-    else flops += 2.0 * px * c.N * c.Kin * c.R * c.S;
+    flops += conv_flops(c, 1);
   }
   void set_seg(ConvRec& c, int s, int buf, int ch0, int Cw, int koff, int mode, int istride, int bn, int bn_c0, int dgrad) {
     SegRec& sr = c.seg[s];
@@ -846,11 +880,21 @@ struct Builder {
     const int YR = new_buf(B, H, Wd, nfl / 2, true, true);
     {
       ConvRec& c = new_conv("dec_out_to_heat_maps.refine0.weight", false, nfl / 2, nfl + raw, 3, 3, 1);
+      // The decoder part of the input is a nearest-x2 upsample, so the conv is evaluated per output parity (e,f) on the
+      // HALF-resolution row grid: the 3x3 taps collapse onto 2x2 half-res source pixels with pre-summed weights (2.25x fewer
+      // MACs in forward and weight gradient; the 1.26 GB/img upsampled tensor never exists).  The raw-input channels are read
+      // at stride 2 with taps shifted by (e,f).
       c.nseg = 2;
-      set_seg(c, 0, U, 0, nfl, 0, G_UP2, 1, hn0, 0, DG_UP2);
-      set_seg(c, 1, inH, 0, raw, nfl, G_PLAIN, 1, hn0, nfl, DG_FLIP);
-      c.B = B; c.Ho = H; c.Wo = Wd; c.obuf = YR; c.och0 = 0;
-      c.phases.push_back({0, 0, taps_conv(3, 3, 1), -1});
+      set_seg(c, 0, U, 0, nfl, 0, G_PLAIN, 1, hn0, 0, DG_UP2);
+      set_seg(c, 1, inH, 0, raw, nfl, G_PLAIN, 2, hn0, nfl, DG_FLIP);
+      c.B = B; c.Ho = H / 2; c.Wo = Wd / 2; c.obuf = YR; c.och0 = 0; c.ostride = 2;
+      c.shared_master = true;
+      c.flops_ref = 2.0 * B * H * Wd * (double)(nfl / 2) * (nfl + raw) * 9.0;
+      for (int e = 0; e < 2; ++e)
+        for (int f = 0; f < 2; ++f) {
+          PhaseRec ph{e, f, taps_up2_phase(e, f), -1, taps_conv_phase_s2(e, f)};
+          c.phases.push_back(ph);
+        }
       finish_conv(c);
     }
     const int hn1 = new_bn("dec_out_to_heat_maps.norm1", nfl / 2);
@@ -939,6 +983,7 @@ struct Builder {
     ops->clear();
     training = true;
     { Op& o = push(OP_MEMSET); o.ms.p = zbbase; o.ms.bytes = 0; /* patched in plan_bind */ }
+    { Op& o = push(OP_MEMSET); o.ms.p = P.grads; o.ms.bytes = (size_t)P.nparams * sizeof(float); }  // unpack may accumulate
     {
       Op& o = push(OP_BCE);
       BceArgs& a = o.bce;

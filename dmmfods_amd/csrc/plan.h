@@ -27,6 +27,8 @@ std::vector<Tap> taps_conv_dgrad(int R, int S, int pad);      // data gradient o
 std::vector<Tap> taps_convT_phase(int py, int px);            // ConvTranspose 3x3 s2 p1, output parity (py,px)
 std::vector<Tap> taps_convT_dgrad();                          // stride-2 gather over the output gradient
 std::vector<Tap> taps_up2_merged_dgrad();                     // 3x3 conv over a nearest-x2 source: 4x4 s2 merged taps
+std::vector<Tap> taps_up2_phase(int e, int f);                // same conv, forward, output parity (e,f): 2x2 merged half-res taps
+std::vector<Tap> taps_conv_phase_s2(int e, int f);            // 3x3 p1 conv sampled at output parity (e,f) from a full-res source
 void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK);
 void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK);
 
