@@ -441,6 +441,7 @@ int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const 
   a.wpack = pd.dst; a.N = d->Cin; a.Npad = pd.Npad;
   a.out = gx; a.ldo = d->Cin; a.Hout = d->H; a.Wout = d->W; a.ostride = ostride;
   a.bx = x; a.ldbx = d->Cin; a.bscale = scale; a.bshift = shift;
+  a.bmean = shift + d->Cin; a.binvstd = shift + 2 * d->Cin;  // test entry point: mean / invstd follow `shift`
   a.red1 = red; a.red2 = red + d->Cin;
   a.accumulate = 0; a.pool2 = pool2;
   HIPCHK(launch_igemm(a, d->dtype, EPI_BNBWD, d->use_mfma != 0, st));

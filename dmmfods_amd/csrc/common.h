@@ -75,8 +75,10 @@ struct ConvArgs {
   int ldbx;
   const float* bscale;
   const float* bshift;
+  const float* bmean;    // batch mean / inverse std of x: the second reduction is sum dz * (x - mean) * invstd
+  const float* binvstd;
   double* red1;    // sum dz
-  double* red2;    // sum dz*x
+  double* red2;    // sum dz*xhat
   int accumulate;  // out += s*dz  instead of  out = s*dz
   int pool2;       // each row is a 2x2-average-pooled pixel: distribute 0.25*acc to the 4 source pixels
 };

@@ -52,12 +52,42 @@ __device__ __forceinline__ void kw_next(KWalk& w, const Seg* seg, int nseg, int 
   }
 }
 
+// Prologue constants of one slot column (8 or 4 channels), loaded once by kernels whose threads keep a fixed channel
+// position (wgrad): BN+ReLU uses k0 = scale, k1 = shift; the effective gradient uses k0..k3 = q, r, q_lo, r_lo.
+template <int S>
+struct SlotK {
+  typedef float fv __attribute__((ext_vector_type(S)));  // vector-typed so that the struct lives in registers
+  fv k0, k1, k2, k3;
+};
+template <int S>
+__device__ __forceinline__ typename SlotK<S>::fv load_fv(const float* p) {
+  typename SlotK<S>::fv v;
+#pragma unroll
+  for (int i = 0; i < S; i += 4) {
+    const f32x4 t = *(const f32x4*)(p + i);
+    v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+  }
+  return v;
+}
+template <int S>
+__device__ __forceinline__ SlotK<S> load_slot_consts(const Seg& sg, int c) {
+  SlotK<S> k;
+  k.k0 = 0.f; k.k1 = 0.f; k.k2 = 0.f; k.k3 = 0.f;
+  if (c >= 0 && c < sg.C) {
+    if (sg.scale != nullptr) { k.k0 = load_fv<S>(sg.scale + c); k.k1 = load_fv<S>(sg.shift + c); }
+    else if (sg.q != nullptr) {
+      k.k0 = load_fv<S>(sg.q + c); k.k1 = load_fv<S>(sg.r + c); k.k2 = load_fv<S>(sg.ql + c); k.k3 = load_fv<S>(sg.rl + c);
+    }
+  }
+  return k;
+}
+
 // One 16-byte slot of the gathered operand for row pixel (b,y,x) at K position (tap, c) of segment sg,
 // with the segment's prologue applied.  Out-of-image taps, channels >= C, taps >= ntaps and invalid rows
 // give zeros (zero padding applies AFTER BN+ReLU, as in conv(relu(bn(x)))).
-template <typename T>
+template <typename T, bool PRE = false>
 __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b, int y, int x, bool rowvalid,
-                                                           int tap, int c) {
+                                                           int tap, int c, const SlotK<TT<T>::SLOT>& pre = SlotK<TT<T>::SLOT>()) {
   constexpr int S = TT<T>::SLOT;
   typedef typename TT<T>::vec V;
   V zero;
@@ -70,7 +100,12 @@ __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b,
 #pragma unroll
     for (int i = 0; i < S; ++i) acc[i] = 0.f;
     const bool bn = sg.scale != nullptr;
-    if (bn) { load_f32s<S>(sg.scale + c, sc); load_f32s<S>(sg.shift + c, sh); }
+    if (bn) {
+      if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) { sc[i] = pre.k0[i]; sh[i] = pre.k1[i]; }
+      } else { load_f32s<S>(sg.scale + c, sc); load_f32s<S>(sg.shift + c, sh); }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const size_t pix = ((size_t)(b * sg.Hs + 2 * y + (a >> 1)) * sg.Ws + (2 * x + (a & 1)));
@@ -99,8 +134,10 @@ __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b,
   if (sg.scale != nullptr) {
     float f[S], sc[S], sh[S];
     vec_to_f32<T>(v, f);
-    load_f32s<S>(sg.scale + c, sc);
-    load_f32s<S>(sg.shift + c, sh);
+    if constexpr (PRE) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) { sc[i] = pre.k0[i]; sh[i] = pre.k1[i]; }
+    } else { load_f32s<S>(sg.scale + c, sc); load_f32s<S>(sg.shift + c, sh); }
 #pragma unroll
     for (int i = 0; i < S; ++i) f[i] = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
     return f32_to_vec<T>(f);
@@ -110,10 +147,15 @@ __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b,
     float f[S], f2[S], q[S], r[S], ql[S], rl[S];
     vec_to_f32<T>(v, f);
     vec_to_f32<T>(v2, f2);
-    load_f32s<S>(sg.q + c, q);
-    load_f32s<S>(sg.r + c, r);
-    load_f32s<S>(sg.ql + c, ql);
-    load_f32s<S>(sg.rl + c, rl);
+    if constexpr (PRE) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) { q[i] = pre.k0[i]; r[i] = pre.k1[i]; ql[i] = pre.k2[i]; rl[i] = pre.k3[i]; }
+    } else {
+      load_f32s<S>(sg.q + c, q);
+      load_f32s<S>(sg.r + c, r);
+      load_f32s<S>(sg.ql + c, ql);
+      load_f32s<S>(sg.rl + c, rl);
+    }
 #pragma unroll
     for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(r[i], f2[i], q[i])) + fmaf(rl[i], f2[i], ql[i]);
     return f32_to_vec<T>(f);

@@ -210,9 +210,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int cv = tid % NCV, rr = tid / NCV;
   const int n = n0 + cv * SLOT;
   const bool colvalid = n < a.N;
-  double s1[SLOT], s2[SLOT];
+  // per-thread partials cover <= 128/RPP rows: float is exact enough here; everything above this level is fp64
+  float s1[SLOT], s2[SLOT];
 #pragma unroll
-  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 
   if (EPI == EPI_STORE) {
     const T* Cs = (const T*)smem;
@@ -225,15 +226,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       float f[SLOT];
       vec_to_f32<T>(v, f);
 #pragma unroll
-      for (int i = 0; i < SLOT; ++i) { const double v = (double)f[i]; s1[i] += v; s2[i] += v * v; }
+      for (int i = 0; i < SLOT; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
     }
     if (a.stat_sum == nullptr) return;
   } else {  // EPI_BNBWD
     const float* Cs = (const float*)smem;
     const T* bx = (const T*)a.bx;
     T* g = (T*)a.out;
-    float sc[SLOT], sh[SLOT];
-    if (colvalid) { load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh); }
+    float sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+    if (colvalid) {
+      load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
+      load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
+    }
     const int nsub = a.pool2 ? 4 : 1;
     const float wgt = a.pool2 ? 0.25f : 1.f;
     for (int row = rr; row < BM; row += RPP) {
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < SLOT; ++i) {
           const float dz = (fmaf(xf[i], sc[i], sh[i]) > 0.f) ? av[i] * wgt : 0.f;
-          s1[i] += (double)dz;
-          s2[i] += (double)dz * (double)xf[i];
+          s1[i] += dz;
+          s2[i] = fmaf(dz, (xf[i] - mu[i]) * is[i], s2[i]);  // sum dz * xhat: centred, so nothing cancels later
           gf[i] = (a.accumulate ? gf[i] : 0.f) + sc[i] * dz;
         }
         *(V*)(g + p * a.ldo + n) = f32_to_vec<T>(gf);
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   if (colvalid) {
 #pragma unroll
     for (int i = 0; i < SLOT; ++i) {
-      atomicAdd(&red[cv * SLOT + i], s1[i]);
-      atomicAdd(&red[BN + cv * SLOT + i], s2[i]);
+      atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
+      atomicAdd(&red[BN + cv * SLOT + i], (double)s2[i]);
     }
   }
   __syncthreads();

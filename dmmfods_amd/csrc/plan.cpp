@@ -394,7 +394,7 @@ struct Builder {
     }
     pd.st = 1;
     pd.w += base_off;
-    pd.Npad = rup(dgrad_seg ? c.seg[seg_index].C : c.N, 32);
+    pd.Npad = dgrad_seg ? rup(c.seg[seg_index].C, c.seg[seg_index].C >= 64 ? 64 : 32) : rup(c.N, 32);
     int chunks = 0;
     for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
     const size_t elems = (size_t)chunks * pd.Npad * BK;
@@ -625,6 +625,7 @@ struct Builder {
       a.ldbx = sb.ld;
       const Bn& bn = bns[sr.bn];
       a.bscale = bn.scale + sr.bn_c0; a.bshift = bn.shift + sr.bn_c0;
+      a.bmean = bn.mean + sr.bn_c0; a.binvstd = bn.invstd + sr.bn_c0;
       a.red1 = bn.red1 + sr.bn_c0; a.red2 = bn.red2 + sr.bn_c0;
       a.accumulate = sb.ginit ? 1 : 0;
       a.pool2 = pool2;
@@ -671,6 +672,7 @@ struct Builder {
     a.ldg = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
     a.argmax = p.argmax;
     a.gy0 = yb.g;
+    a.mean = bns[p.bn].mean; a.invstd = bns[p.bn].invstd;
     a.red1 = bns[p.bn].red1; a.red2 = bns[p.bn].red2;
     tag(o, "maxpool.bwd", "pool0", 0, (2.0 * yb.B * yb.H * yb.W + 2.0 * ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
     yb.ginit = true;

@@ -35,7 +35,7 @@ struct BnFinalizeArgs {
 
 struct BnBwdFinalizeArgs {
   const double* red1;  // sum dz
-  const double* red2;  // sum dz*x
+  const double* red2;  // sum dz*xhat
   const float* mean;
   const float* invstd;
   const float* scale;
@@ -75,6 +75,8 @@ struct MaxpoolBwdArgs {
   const float* r;
   const float* ql;
   const float* rl;
+  const float* mean;    // norm0 batch statistics of y0
+  const float* invstd;
   int ldg, Hp, Wp;
   const unsigned char* argmax;
   void* gy0;  // (B, H0, W0, ld0): s * dz0

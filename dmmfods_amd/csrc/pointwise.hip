@@ -103,7 +103,7 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   if (c >= a.C) return;
   const double S1 = a.red1[c], S2 = a.red2[c];
   const double mu = a.mean[c], is = a.invstd[c];
-  const double dotp = (S2 - mu * S1) * is;  // sum dz * xhat
+  const double dotp = S2;  // sum dz * xhat, reduced in centred form by the producing kernel
   a.dgamma[c] = (float)(dotp * a.grad_scale);
   a.dbeta[c] = (float)(S1 * a.grad_scale);
   if (a.qd != nullptr) {
@@ -230,6 +230,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
   load_f32s<SLOT>(a.r + c, rr);
   load_f32s<SLOT>(a.ql + c, qlo);
   load_f32s<SLOT>(a.rl + c, rlo);
+  float mu[SLOT], istd[SLOT];
+  load_f32s<SLOT>(a.mean + c, mu);
+  load_f32s<SLOT>(a.invstd + c, istd);
 #pragma unroll
   for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
   const int npix = a.B * a.H0 * a.W0;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
       for (int i = 0; i < SLOT; ++i) {
         const float dz = (fmaf(yf[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
         s1[i] += (double)dz;
-        s2[i] += (double)dz * (double)yf[i];
+        s2[i] += (double)(dz * ((yf[i] - mu[i]) * istd[i]));
         o[i] = sc[i] * dz;
       }
       *(V*)(gy0 + (size_t)p * a.ld0 + c) = f32_to_vec<T>(o);

@@ -46,7 +46,7 @@ __device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
 }
 
 template <typename T, int WBN, bool MFMA>
-__global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
   constexpr int KCH = KW / BK;  // chunks per workgroup
@@ -92,6 +92,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
   }
   const int cd = tid % NCD, rgd = tid / NCD;
   const int nD = n0 + cd * SLOT;
+  // every thread keeps its channel position for the whole kernel: load the prologue constants once
+  const SlotK<SLOT> preQ = load_slot_consts<SLOT>(a.seg[ks], ktap < a.seg[ks].ntaps ? kc : -1);
+  const SlotK<SLOT> preP = load_slot_consts<SLOT>(a.dy, nD < a.N ? nD : -1);
 
   auto fill_rowtab = [&](int which, int mt) {
     if (tid < BMW) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int4 e = rowtab[which * BMW + rga + i * RGA];
-      areg[i] = gather_slot<T>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc);
+      areg[i] = gather_slot<T, true>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc, preQ);
     }
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
       for (int u = 0; u < SLOT; ++u) v[u] = (T)0;
       if (row < BMW) {
         const int4 e = rowtab[which * BMW + row];
-        if (nD < a.N) v = gather_slot<T>(a.dy, e.x, e.y, e.z, e.w > 0, 0, nD);
+        if (nD < a.N) v = gather_slot<T, true>(a.dy, e.x, e.y, e.z, e.w > 0, 0, nD, preP);
       }
       dreg[i] = v;
     }

@@ -136,7 +136,8 @@ int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, cons
 int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, float* dw,
                    void* scratch, void* stream);
 /* BN+ReLU-fused data gradient: gx (T, NHWC like x) = scale * relu'(x*scale+shift) * conv_dgrad(dy); red: 2*Cin doubles
- * (sum dz, sum dz*x; zeroed by the callee). */
+ * (sum dz, sum dz*xhat with xhat = (x - mean)*invstd; zeroed by the callee).  `shift` points at 3*Cin floats:
+ * shift, mean, invstd. */
 int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
                    void* gx, double* red, void* scratch, void* stream);
 

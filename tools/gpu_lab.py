@@ -61,7 +61,10 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
     nsc = L.dmm_conv_scratch_bytes(C.byref(d))
     scratch = torch.zeros(nsc, dtype=torch.uint8, device=DEV)
     xd = nhwc(x, dt).to(DEV)
-    wd, sd, hd = w.to(DEV), scale.to(DEV), shift.to(DEV)
+    # dgrad entry point wants [shift | mean | invstd]; any mean/invstd define xhat for the second reduction
+    mean = torch.randn(Cin, generator=g)
+    invstd = torch.rand(Cin, generator=g) + 0.5
+    wd, sd, hd = w.to(DEV), scale.to(DEV), torch.cat([shift, mean, invstd]).to(DEV)
     yd = torch.full((B, y.shape[2], y.shape[3], Cout), float("nan"), dtype=dt, device=DEV)
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
     st = _lib.stream_ptr()
@@ -92,7 +95,8 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
         torch.cuda.synchronize()
         res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref)
         res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)))
-        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xq.double()).sum(dim=(0, 2, 3)))
+        xhat = (xq.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xhat).sum(dim=(0, 2, 3)))
     tol = 3e-3 if dtype == 1 else 2e-5
     bad = [k for k, v in res.items() if not (v < tol)]
     print(f"{'FAIL' if bad else 'ok  '} {name:28s} dt={dtype} mfma={mfma} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
