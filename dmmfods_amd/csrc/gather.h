@@ -82,6 +82,35 @@ __device__ __forceinline__ SlotK<S> load_slot_consts(const Seg& sg, int c) {
   return k;
 }
 
+// The same constants read from an LDS image built once per workgroup (stage_consts): [k0 | k1 | k2 | k3] x Cst floats.
+template <int S>
+__device__ __forceinline__ SlotK<S> lds_slot_consts(const float* lk, int cst, int narr, int c) {
+  SlotK<S> k;
+  k.k0 = 0.f; k.k1 = 0.f; k.k2 = 0.f; k.k3 = 0.f;
+  if (narr >= 2 && c >= 0 && c < cst) {
+    k.k0 = load_fv<S>(lk + c);
+    k.k1 = load_fv<S>(lk + cst + c);
+    if (narr == 4) { k.k2 = load_fv<S>(lk + 2 * cst + c); k.k3 = load_fv<S>(lk + 3 * cst + c); }
+  }
+  return k;
+}
+// Cooperative fill of that image; returns the number of floats used.  Call before a __syncthreads().
+__device__ __forceinline__ int stage_consts(const Seg& sg, float* lk, int tid, int nthreads) {
+  const int cst = sg.C;
+  if (sg.scale != nullptr) {
+    for (int i = tid; i < cst; i += nthreads) { lk[i] = sg.scale[i]; lk[cst + i] = sg.shift[i]; }
+    return 2 * cst;
+  }
+  if (sg.q != nullptr) {
+    for (int i = tid; i < cst; i += nthreads) {
+      lk[i] = sg.q[i]; lk[cst + i] = sg.r[i]; lk[2 * cst + i] = sg.ql[i]; lk[3 * cst + i] = sg.rl[i];
+    }
+    return 4 * cst;
+  }
+  return 0;
+}
+__host__ __device__ inline int seg_const_floats(const Seg& sg) { return sg.scale ? 2 * sg.C : (sg.q ? 4 * sg.C : 0); }
+
 // One 16-byte slot of the gathered operand for row pixel (b,y,x) at K position (tap, c) of segment sg,
 // with the segment's prologue applied.  Out-of-image taps, channels >= C, taps >= ntaps and invalid rows
 // give zeros (zero padding applies AFTER BN+ReLU, as in conv(relu(bn(x)))).
@@ -161,6 +190,69 @@ __device__ __forceinline__ typename TT<T>::vec gather_slot(const Seg& sg, int b,
     return f32_to_vec<T>(f);
   }
   return v;
+}
+
+// ---- split gather (issue-early / write-late): `gather_issue` only computes addresses and issues the global loads, so
+// they stay in flight while the MFMAs of the current K-step run; `gather_finish` applies the prologue one step later,
+// just before the slot is written to LDS.  state: 0 = zero slot, 1 = raw data pending, 2 = already final (pool mode).
+template <typename T>
+struct RawSlot {
+  typename TT<T>::vec v, v2;
+  int state;
+};
+
+template <typename T>
+__device__ __forceinline__ RawSlot<T> gather_issue(const Seg& sg, int b, int y, int x, bool rowvalid, int tap, int c,
+                                                    const SlotK<TT<T>::SLOT>& kpool) {
+  constexpr int S = TT<T>::SLOT;
+  typedef typename TT<T>::vec V;
+  RawSlot<T> r;
+#pragma unroll
+  for (int i = 0; i < S; ++i) { r.v[i] = (T)0; r.v2[i] = (T)0; }
+  r.state = 0;
+  if (!rowvalid || tap >= sg.ntaps || c >= sg.C) return r;
+  if (sg.mode == G_POOL2) {  // four loads + averaging: rare (transitions), done synchronously
+    r.v = gather_slot<T, true>(sg, b, y, x, rowvalid, tap, c, kpool);
+    r.state = 2;
+    return r;
+  }
+  const int t = sg.taps[tap];
+  const int dy = (int)(signed char)(t & 0xff), dx = (int)(signed char)((t >> 8) & 0xff);
+  int sy = y * sg.istride + dy, sx = x * sg.istride + dx;
+  if (sg.mode == G_UP2) {
+    if (sy < 0 || sx < 0 || sy >= 2 * sg.Hs || sx >= 2 * sg.Ws) return r;
+    sy >>= 1;
+    sx >>= 1;
+  } else {
+    if (sy < 0 || sx < 0 || sy >= sg.Hs || sx >= sg.Ws) return r;
+  }
+  const size_t pix = ((size_t)(b * sg.Hs + sy) * sg.Ws + sx);
+  r.v = *(const V*)((const T*)sg.src + pix * sg.ld + c);
+  if (sg.q != nullptr) r.v2 = *(const V*)((const T*)sg.src2 + pix * sg.ld2 + c);
+  r.state = 1;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec gather_finish(const Seg& sg, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {
+  constexpr int S = TT<T>::SLOT;
+  if (r.state != 1) return r.v;  // zero or already final
+  if (sg.scale != nullptr) {
+    float f[S];
+    vec_to_f32<T>(r.v, f);
+#pragma unroll
+    for (int i = 0; i < S; ++i) f[i] = fmaxf(fmaf(f[i], k.k0[i], k.k1[i]), 0.f);
+    return f32_to_vec<T>(f);
+  }
+  if (sg.q != nullptr) {
+    float f[S], f2[S];
+    vec_to_f32<T>(r.v, f);
+    vec_to_f32<T>(r.v2, f2);
+#pragma unroll
+    for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
+    return f32_to_vec<T>(f);
+  }
+  return r.v;
 }
 
 // Decompose a row index into (b, y, x) of the row grid.

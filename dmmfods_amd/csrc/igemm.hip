@@ -41,7 +41,7 @@ struct IgemmSmem {
   static constexpr int STAGE_T = BM * STAGE_PITCH_T * (int)sizeof(T);
   static constexpr int STAGE_F = BM * STAGE_PITCH_F * 4;
   static constexpr int EXTRA = BM * 4 + 2 * BN * 8;  // rowpix + fp64 reduction scratch
-  static constexpr int bytes(int epi) {
+  static constexpr int bytes(int epi) {  // without the per-launch prologue-constant image
     int st = (epi == EPI_STORE) ? STAGE_T : STAGE_F;
     int m = MAIN > st ? MAIN : st;
     return m + EXTRA;
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   // the gradient, and an error of 1e-7*sum|dz| in that mean is a coherent offset that the next weight-gradient GEMM
   // amplifies over all pixels (torch's CPU BatchNorm accumulates in double for the same reason).
   double* red = (double*)(smem + MAINB + BM * 4);
+  // prologue constants (scale/shift or q/r/q_lo/r_lo) of every segment, staged once: the gather then issues ONE vector
+  // memory instruction per slot instead of five (the L1-hit constant loads were saturating the texture-address path)
+  float* lk0 = (float*)(smem + MAINB + SM::EXTRA);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -90,6 +93,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     rowpix[tid] = m < a.M ? (pb * a.Hout + py_ * a.ostride + a.py) * a.Wout + px_ * a.ostride + a.px : -1;
   }
   if (tid < 2 * BN) red[tid] = 0.0;
+  const int nk0 = stage_consts(a.seg[0], lk0, tid, NTHREADS);
+  float* lk1 = lk0 + nk0;
+  if (a.nseg > 1) stage_consts(a.seg[1], lk1, tid, NTHREADS);
+  __syncthreads();
 
   int total = 0;
   for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
@@ -104,11 +111,19 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   kw_enter<SLOT>(kw, a.seg, 0, j);
   const T* wp = (const T*)a.wpack;
 
-  V areg[2], breg[BSLOTS];
+  // issue-early / write-late: load_chunk only issues the global loads of the next K-step; the prologue (BN+ReLU or the
+  // deferred-gradient correction) runs in store_chunk one iteration later, after that step's MFMAs.
+  RawSlot<T> araw[2];
+  V breg[BSLOTS];
+  int sv_s = 0, sv_c = 0, sv_narr = 0;
   auto load_chunk = [&](int gchunk) {
     const Seg& sg = a.seg[kw.s];
+    const int narr = sg.scale ? 2 : (sg.q ? 4 : 0);
+    sv_s = kw.s; sv_c = kw.c; sv_narr = kw.tap < sg.ntaps ? narr : 0;
+    SlotK<SLOT> kpool;
+    if (sg.mode == G_POOL2) kpool = lds_slot_consts<SLOT>(kw.s ? lk1 : lk0, sg.C, sv_narr, kw.c);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) areg[i] = gather_slot<T>(sg, rb[i], ry[i], rx[i], rv[i], kw.tap, kw.c);
+    for (int i = 0; i < 2; ++i) araw[i] = gather_issue<T>(sg, rb[i], ry[i], rx[i], rv[i], kw.tap, kw.c, kpool);
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
       const int q = tid + i * NTHREADS;
@@ -121,8 +136,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   auto store_chunk = [&](int buf) {
     unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
     unsigned char* Bs = As + SM::A_BYTES;
+    const Seg& sg = a.seg[sv_s];
+    const SlotK<SLOT> kk = lds_slot_consts<SLOT>(sv_s ? lk1 : lk0, sg.C, sv_narr, sv_c);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(V*)(As + (ar0 + 64 * i) * ROWB + j * 16) = areg[i];
+    for (int i = 0; i < 2; ++i) *(V*)(As + (ar0 + 64 * i) * ROWB + j * 16) = gather_finish<T>(sg, araw[i], kk);
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
       const int q = tid + i * NTHREADS;
@@ -289,14 +306,17 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   const int mtiles = (a.M + BM - 1) / BM;
   const int ntiles = a.Npad / BN;
   dim3 grid(mtiles * ntiles), block(NTHREADS);
-  const int smem = IgemmSmem<T, BN>::bytes(EPI);
+  int kfl = 0;
+  for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
+  const int smem = IgemmSmem<T, BN>::bytes(EPI) + kfl * 4 + 16;
   auto kern = mfma ? igemm_kernel<T, BN, EPI, true> : igemm_kernel<T, BN, EPI, false>;
-  static bool attr_done[2] = {false, false};
-  if (smem > 48 * 1024 && !attr_done[mfma]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  static int attr_bytes[2] = {0, 0};
+  if (smem > 48 * 1024 && smem > attr_bytes[mfma]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_done[mfma] = true;
+    attr_bytes[mfma] = 160 * 1024;
   }
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, grid, block, smem, st, a);
   return hipGetLastError();
 }

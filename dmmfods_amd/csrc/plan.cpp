@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -243,6 +244,7 @@ struct Bump {
 
 struct Buf {
   int B, H, W, ld;
+  int cw = 0;             // logical channel count (ld may carry padding)
   uint8_t* x = nullptr;   // activations (T)
   uint8_t* g = nullptr;   // raw gradient (T), same layout
   double* ssum = nullptr; // per-channel sum / sum^2 of x
@@ -331,9 +333,13 @@ struct Builder {
     return *it->second;
   }
 
-  int new_buf(int B, int H, int W_, int ld, bool grad, bool stats) {
+  int new_buf(int B, int H, int W_, int cw, bool grad, bool stats) {
     Buf b;
-    b.B = B; b.H = H; b.W = W_; b.ld = ld;
+    // Pixel pitch: power-of-two pitches make every workgroup hit the same HBM channels at the same time (all of them read
+    // the same 64-byte column window of their rows as they walk K in step), so wide buffers get an odd multiple of 64 B.
+    int ld = cw;
+    if (pad_pitch && cw >= 64 && (cw * esz) % 256 == 0) ld = cw + 64 / esz;
+    b.B = B; b.H = H; b.W = W_; b.ld = ld; b.cw = cw;
     const size_t n = (size_t)B * H * W_ * ld;
     b.x = wptr<uint8_t>(n * esz);
     if (grad) b.g = wptr<uint8_t>(n * esz);
@@ -848,7 +854,7 @@ struct Builder {
       const int inb = X[g.nb - 1 - j];
       const Buf I = bufs[inb];  // by value: new_buf() may reallocate `bufs`
       const int nin = g.nin[j], nf = g.nf[j];
-      if (I.ld != nin) throw std::runtime_error("decoder width mismatch");
+      if (I.cw != nin) throw std::runtime_error("decoder width mismatch");
       const int n0 = new_bn(p + ".norm0", nin);
       bn_range(n0, inb, 0, 0, nin);
       const int Rb = new_buf(I.B, I.H, I.W, nf, true, true);
@@ -943,6 +949,7 @@ struct Builder {
     tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
   }
 
+  bool pad_pitch = getenv("DMM_PITCH_PAD") != nullptr;  // measured: no effect on MI355X for this access pattern; off
   PackDesc* pack_dev = nullptr;
   int* prefix_dev = nullptr;
   int total_rows = 0;

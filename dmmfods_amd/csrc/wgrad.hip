@@ -19,7 +19,7 @@ namespace dmm {
 constexpr int KW = 128;  // k elements per workgroup
 
 template <typename T> struct WgCfg;
-template <> struct WgCfg<f16> { static constexpr int BMW = 128; };
+template <> struct WgCfg<f16> { static constexpr int BMW = 64; };
 template <> struct WgCfg<float> { static constexpr int BMW = 32; };
 
 template <typename T, int WBN>
@@ -111,34 +111,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     }
   };
 
-  V areg[LA], dreg[LD];
+  // issue-early / write-late (see igemm.hip): raw loads now, prologue when the tile is written to LDS one step later
+  RawSlot<T> araw[LA], draw[LD];
   auto load_tiles = [&](int which) {
     const Seg& sg = a.seg[ks];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int4 e = rowtab[which * BMW + rga + i * RGA];
-      areg[i] = gather_slot<T, true>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc, preQ);
+      araw[i] = gather_issue<T>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc, preQ);
     }
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int row = rgd + i * RGD;
-      V v;
-#pragma unroll
-      for (int u = 0; u < SLOT; ++u) v[u] = (T)0;
-      if (row < BMW) {
-        const int4 e = rowtab[which * BMW + row];
-        if (nD < a.N) v = gather_slot<T, true>(a.dy, e.x, e.y, e.z, e.w > 0, 0, nD, preP);
-      }
-      dreg[i] = v;
+      int4 e = {0, 0, 0, 0};
+      if (row < BMW) e = rowtab[which * BMW + row];
+      draw[i] = gather_issue<T>(a.dy, e.x, e.y, e.z, e.w > 0 && nD < a.N, 0, nD < a.N ? nD : 0, preP);
     }
   };
   auto store_tiles = [&]() {
+    const Seg& sg = a.seg[ks];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = areg[i];
+    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = gather_finish<T>(sg, araw[i], preQ);
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int row = rgd + i * RGD;
-      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = dreg[i];
+      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = gather_finish<T>(a.dy, draw[i], preP);
     }
   };
 
@@ -261,7 +258,7 @@ static hipError_t launch_wt(const WgradArgs& a, bool mfma, hipStream_t st) {
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   const int BK = dtype == DT_F16 ? 32 : 16;
-  const int bmw = dtype == DT_F16 ? 128 : 32;
+  const int bmw = dtype == DT_F16 ? 64 : 32;
   int total = 0;
   for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
   a.kgroups = (total * BK + KW - 1) / KW;
