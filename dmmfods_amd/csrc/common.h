@@ -30,7 +30,9 @@ template <> struct TT<f16> {
 constexpr int MAX_TAPS = 52;
 constexpr int BM = 128;        // rows (pixels) per workgroup tile
 constexpr int NTHREADS = 256;  // 4 waves of 64
-constexpr int ROWB = 80;       // LDS bytes per tile row: 64 B of K-chunk + 16 B pad (conflict-free ds_read_b128)
+constexpr int ROWB = 64;       // LDS bytes per tile row = one K-chunk; the four 16-byte slots of a row are XOR-swizzled
+                               // with (row >> 2) & 3, which makes ds_read_b128 conflict-free for its 16-lane groups
+                               // {0-3,12-15,20-27}, ... (each group then covers 4 bank quarters x 4 distinct slots)
 
 enum GatherMode { G_PLAIN = 0, G_UP2 = 1, G_POOL2 = 2 };
 enum Epilogue { EPI_STORE = 0, EPI_BNBWD = 1, EPI_LOGITS = 2 };

@@ -30,11 +30,13 @@ template <> struct Mma<float> {
   }
 };
 
+constexpr int KS = 2;  // K-chunks per pipeline stage: twice the bytes in flight and twice the MFMAs per barrier
+
 template <typename T, int BN>
 struct IgemmSmem {
   static constexpr int SLOT = TT<T>::SLOT;
-  static constexpr int A_BYTES = BM * ROWB;
-  static constexpr int B_BYTES = BN * ROWB;
+  static constexpr int A_BYTES = KS * BM * ROWB;
+  static constexpr int B_BYTES = KS * BN * ROWB;
   static constexpr int STAGE_PITCH_T = BN + SLOT;  // elements of T
   static constexpr int STAGE_PITCH_F = BN + 4;     // floats
   static constexpr int MAIN = 2 * (A_BYTES + B_BYTES);
@@ -48,7 +50,9 @@ struct IgemmSmem {
   }
 };
 
-template <typename T, int BN, int EPI, bool MFMA>
+// LIN = lean path for plain 1x1 convolutions (one segment, one tap, unit stride, same grid): the source pixel of a row
+// is the row itself, so the K loop needs no tap walker, coordinates or bounds tests.
+template <typename T, int BN, int EPI, bool MFMA, bool LIN>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
@@ -113,62 +117,113 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 
   // issue-early / write-late: load_chunk only issues the global loads of the next K-step; the prologue (BN+ReLU or the
   // deferred-gradient correction) runs in store_chunk one iteration later, after that step's MFMAs.
-  RawSlot<T> araw[2];
-  V breg[BSLOTS];
-  int sv_s = 0, sv_c = 0, sv_narr = 0;
-  auto load_chunk = [&](int gchunk) {
-    const Seg& sg = a.seg[kw.s];
-    const int narr = sg.scale ? 2 : (sg.q ? 4 : 0);
-    sv_s = kw.s; sv_c = kw.c; sv_narr = kw.tap < sg.ntaps ? narr : 0;
-    SlotK<SLOT> kpool;
-    if (sg.mode == G_POOL2) kpool = lds_slot_consts<SLOT>(kw.s ? lk1 : lk0, sg.C, sv_narr, kw.c);
+  RawSlot<T> araw[KS][2];
+  V breg[KS][BSLOTS];
+  int sv_s[KS], sv_c[KS], sv_narr[KS];
+  int gnext = 0;  // next global chunk to issue
+  auto load_stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) araw[i] = gather_issue<T>(sg, rb[i], ry[i], rx[i], rv[i], kw.tap, kw.c, kpool);
+    for (int u = 0; u < KS; ++u) {
+      const int gchunk = gnext++;
+      const bool live = gchunk < total;
+      if constexpr (LIN) {
+        const Seg& sg = a.seg[0];
+        const int c = gchunk * BK + j * SLOT;
+        const bool cv = live && c < sg.C;
+        sv_s[u] = 0; sv_c[u] = c; sv_narr[u] = cv ? (sg.scale ? 2 : (sg.q ? 4 : 0)) : 0;
 #pragma unroll
-    for (int i = 0; i < BSLOTS; ++i) {
-      const int q = tid + i * NTHREADS;
-      if (q < BN * 4) {
-        const int n = q >> 2, jj = q & 3;
-        breg[i] = *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT);
+        for (int i = 0; i < 2; ++i) {
+          RawSlot<T>& rs = araw[u][i];
+#pragma unroll
+          for (int e = 0; e < SLOT; ++e) { rs.v[e] = (T)0; rs.v2[e] = (T)0; }
+          rs.state = 0;
+          if (cv && rv[i]) {
+            const size_t off = (size_t)(m0 + ar0 + 64 * i) * sg.ld + c;
+            rs.v = *(const V*)((const T*)sg.src + off);
+            if (sg.q != nullptr) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)(m0 + ar0 + 64 * i) * sg.ld2 + c);
+            rs.state = 1;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+          const int q = tid + i * NTHREADS;
+          if (q < BN * 4) {
+            const int n = q >> 2, jj = q & 3;
+            V z;
+#pragma unroll
+            for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+            breg[u][i] = live ? *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT) : z;
+          }
+        }
+        continue;
       }
+      const Seg& sg = a.seg[live ? kw.s : 0];
+      const int narr = sg.scale ? 2 : (sg.q ? 4 : 0);
+      sv_s[u] = live ? kw.s : 0; sv_c[u] = kw.c; sv_narr[u] = (live && kw.tap < sg.ntaps) ? narr : 0;
+      SlotK<SLOT> kpool;
+      if (sg.mode == G_POOL2) kpool = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], kw.c);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) araw[u][i] = gather_issue<T>(sg, rb[i], ry[i], rx[i], rv[i] && live, kw.tap, kw.c, kpool);
+#pragma unroll
+      for (int i = 0; i < BSLOTS; ++i) {
+        const int q = tid + i * NTHREADS;
+        if (q < BN * 4) {
+          const int n = q >> 2, jj = q & 3;
+          V z;
+#pragma unroll
+          for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+          breg[u][i] = live ? *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT) : z;
+        }
+      }
+      if (live && gchunk + 1 < total) kw_next<SLOT>(kw, a.seg, a.nseg, j);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_stage = [&](int buf) {
     unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
     unsigned char* Bs = As + SM::A_BYTES;
-    const Seg& sg = a.seg[sv_s];
-    const SlotK<SLOT> kk = lds_slot_consts<SLOT>(sv_s ? lk1 : lk0, sg.C, sv_narr, sv_c);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(V*)(As + (ar0 + 64 * i) * ROWB + j * 16) = gather_finish<T>(sg, araw[i], kk);
+    for (int u = 0; u < KS; ++u) {
+      const Seg& sg = a.seg[sv_s[u]];
+      const SlotK<SLOT> kk = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], sv_c[u]);
 #pragma unroll
-    for (int i = 0; i < BSLOTS; ++i) {
-      const int q = tid + i * NTHREADS;
-      if (q < BN * 4) *(V*)(Bs + (q >> 2) * ROWB + (q & 3) * 16) = breg[i];
+      for (int i = 0; i < 2; ++i) {
+        const int row = u * BM + ar0 + 64 * i;
+        *(V*)(As + row * ROWB + ((j ^ ((row >> 2) & 3)) << 4)) = gather_finish<T>(sg, araw[u][i], kk);
+      }
+#pragma unroll
+      for (int i = 0; i < BSLOTS; ++i) {
+        const int q = tid + i * NTHREADS;
+        if (q < BN * 4) {
+          const int row = u * BN + (q >> 2);
+          *(V*)(Bs + row * ROWB + (((q & 3) ^ ((row >> 2) & 3)) << 4)) = breg[u][i];
+        }
+      }
     }
   };
 
   const int r = lane & 31, h = lane >> 5;
-  load_chunk(0);
-  for (int it = 0; it < total; ++it) {
+  const int nstages = (total + KS - 1) / KS;
+  load_stage();
+  for (int it = 0; it < nstages; ++it) {
     const int buf = it & 1;
-    store_chunk(buf);
+    store_stage(buf);
     __syncthreads();
-    if (it + 1 < total) {
-      kw_next<SLOT>(kw, a.seg, a.nseg, j);
-      load_chunk(it + 1);
-    }
+    if (it + 1 < nstages) load_stage();
     const unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
     const unsigned char* Bs = As + SM::A_BYTES;
     if (MFMA) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const V av = *(const V*)(As + (32 * wave + r) * ROWB + s * 32 + h * 16);
+      for (int u = 0; u < KS; ++u)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const V bv = *(const V*)(Bs + (32 * t + r) * ROWB + s * 32 + h * 16);
-          Mma<T>::run(acc[t], av, bv);
+        for (int s = 0; s < 2; ++s) {
+          const int sw = ((2 * s + h) ^ ((r >> 2) & 3)) << 4;  // BM, BN and 32 are multiples of 16: swizzle depends on r only
+          const V av = *(const V*)(As + (u * BM + 32 * wave + r) * ROWB + sw);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const V bv = *(const V*)(Bs + (u * BN + 32 * t + r) * ROWB + sw);
+            Mma<T>::run(acc[t], av, bv);
+          }
         }
-      }
     } else {
       // scalar check path with the same accumulator layout as the MFMA (debug / bring-up)
 #pragma unroll
@@ -176,10 +231,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const T* ap = (const T*)(As + row * ROWB);
-          const T* bp = (const T*)(Bs + (32 * t + r) * ROWB);
           float s = 0.f;
-          for (int k = 0; k < BK; ++k) s = fmaf(to_f32(ap[k]), to_f32(bp[k]), s);
+          for (int u = 0; u < KS; ++u) {
+            const T* ap = (const T*)(As + (u * BM + row) * ROWB);
+            const T* bp = (const T*)(Bs + (u * BN + 32 * t + r) * ROWB);
+            for (int k = 0; k < BK; ++k) {
+              const int ka = (((k / SLOT) ^ ((row >> 2) & 3)) * SLOT) + k % SLOT;
+              const int kb = (((k / SLOT) ^ ((r >> 2) & 3)) * SLOT) + k % SLOT;
+              s = fmaf(to_f32(ap[ka]), to_f32(bp[kb]), s);
+            }
+          }
           acc[t][i] += s;
         }
     }
@@ -309,12 +370,16 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   int kfl = 0;
   for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
   const int smem = IgemmSmem<T, BN>::bytes(EPI) + kfl * 4 + 16;
-  auto kern = mfma ? igemm_kernel<T, BN, EPI, true> : igemm_kernel<T, BN, EPI, false>;
-  static int attr_bytes[2] = {0, 0};
-  if (smem > 48 * 1024 && smem > attr_bytes[mfma]) {
+  const Seg& s0 = a.seg[0];
+  const bool lin = mfma && a.nseg == 1 && s0.ntaps == 1 && s0.taps[0] == 0 && s0.mode == G_PLAIN && s0.istride == 1 &&
+                   s0.Hs == a.Ho && s0.Ws == a.Wo;
+  auto kern = !mfma ? igemm_kernel<T, BN, EPI, false, false> : (lin ? igemm_kernel<T, BN, EPI, true, true> : igemm_kernel<T, BN, EPI, true, false>);
+  const int ai = mfma ? (lin ? 2 : 1) : 0;
+  static int attr_bytes[3] = {0, 0, 0};
+  if (smem > 48 * 1024 && smem > attr_bytes[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_bytes[mfma] = 160 * 1024;
+    attr_bytes[ai] = 160 * 1024;
   }
   if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, grid, block, smem, st, a);
