@@ -11,6 +11,8 @@
 // Tile: 128 rows x BN columns per 256-thread workgroup; each wave owns 32 rows x BN columns as BN/32
 // v_mfma_f32_32x32x16_f16 (or 32x32x2_f32) accumulators.  K advances in 64-byte chunks, register-staged
 // through a double-buffered LDS image with 80-byte rows (conflict-free ds_read_b128).
+#include <cstdlib>
+
 #include "common.h"
 #include "gather.h"
 
@@ -398,8 +400,15 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
   return launch_bn<T, 32, EPI>(a, mfma, st);
 }
 
+hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // halo.hip
+
 hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
+  static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;
+  if (mfma && !no_halo) {  // multi-tap layers whose weights fit in LDS may take the halo-tile kernel
+    const hipError_t e = launch_halo(a, dtype, epi, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (dtype == DT_F16) {
     if (epi == EPI_STORE) return launch_epi<f16, EPI_STORE>(a, mfma, st);
     if (epi == EPI_BNBWD) return launch_epi<f16, EPI_BNBWD>(a, mfma, st);
