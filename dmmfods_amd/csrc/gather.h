@@ -94,6 +94,18 @@ __device__ __forceinline__ SlotK<S> lds_slot_consts(const float* lk, int cst, in
   }
   return k;
 }
+template <int S, int NARR>
+__device__ __forceinline__ SlotK<S> lds_slot_consts_n(const float* lk, int cst, int c) {
+  SlotK<S> k;
+  k.k0 = 0.f; k.k1 = 0.f; k.k2 = 0.f; k.k3 = 0.f;
+  if constexpr (NARR >= 2) {
+    const int cc = c < cst ? c : 0;  // tails read channel 0's constants; their slots are zeroed by state anyway
+    k.k0 = load_fv<S>(lk + cc);
+    k.k1 = load_fv<S>(lk + cst + cc);
+    if constexpr (NARR == 4) { k.k2 = load_fv<S>(lk + 2 * cst + cc); k.k3 = load_fv<S>(lk + 3 * cst + cc); }
+  }
+  return k;
+}
 // Cooperative fill of that image; returns the number of floats used.  Call before a __syncthreads().
 __device__ __forceinline__ int stage_consts(const Seg& sg, float* lk, int tid, int nthreads) {
   const int cst = sg.C;
@@ -233,9 +245,29 @@ __device__ __forceinline__ RawSlot<T> gather_issue(const Seg& sg, int b, int y, 
   return r;
 }
 
-template <typename T>
+// PRO: -1 = decide at run time from the segment; 0 = none; 1 = BN+ReLU; 2 = effective gradient (compile-time variants carry
+// only their own straight-line code)
+template <typename T, int PRO = -1>
 __device__ __forceinline__ typename TT<T>::vec gather_finish(const Seg& sg, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {
   constexpr int S = TT<T>::SLOT;
+  if constexpr (PRO >= 0) {
+    typename TT<T>::vec out = r.v;
+    if constexpr (PRO == 1) {
+      float f[S];
+      vec_to_f32<T>(r.v, f);
+#pragma unroll
+      for (int i = 0; i < S; ++i) f[i] = fmaxf(fmaf(f[i], k.k0[i], k.k1[i]), 0.f);
+      out = f32_to_vec<T>(f);
+    } else if constexpr (PRO == 2) {
+      float f[S], f2[S];
+      vec_to_f32<T>(r.v, f);
+      vec_to_f32<T>(r.v2, f2);
+#pragma unroll
+      for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
+      out = f32_to_vec<T>(f);
+    }
+    return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
+  }
   if (r.state != 1) return r.v;  // zero or already final
   if (sg.scale != nullptr) {
     float f[S];

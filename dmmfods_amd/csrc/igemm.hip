@@ -54,7 +54,8 @@ struct IgemmSmem {
 
 // LIN = lean path for plain 1x1 convolutions (one segment, one tap, unit stride, same grid): the source pixel of a row
 // is the row itself, so the K loop needs no tap walker, coordinates or bounds tests.
-template <typename T, int BN, int EPI, bool MFMA, bool LIN>
+// PRO = prologue of every segment, fixed at compile time for the MFMA variants (-1: look at the segment at run time).
+template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
           if (cv && rv[i]) {
             const size_t off = (size_t)(m0 + ar0 + 64 * i) * sg.ld + c;
             rs.v = *(const V*)((const T*)sg.src + off);
-            if (sg.q != nullptr) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)(m0 + ar0 + 64 * i) * sg.ld2 + c);
+            if (PRO == 2 || (PRO < 0 && sg.q != nullptr)) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)(m0 + ar0 + 64 * i) * sg.ld2 + c);
             rs.state = 1;
           }
         }
@@ -186,11 +187,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int u = 0; u < KS; ++u) {
       const Seg& sg = a.seg[sv_s[u]];
-      const SlotK<SLOT> kk = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], sv_c[u]);
+      SlotK<SLOT> kk;
+      if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(sv_s[u] ? lk1 : lk0, sg.C, sv_c[u]);
+      else kk = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], sv_c[u]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = u * BM + ar0 + 64 * i;
-        *(V*)(As + row * ROWB + ((j ^ ((row >> 2) & 3)) << 4)) = gather_finish<T>(sg, araw[u][i], kk);
+        *(V*)(As + row * ROWB + ((j ^ ((row >> 2) & 3)) << 4)) = gather_finish<T, PRO>(sg, araw[u][i], kk);
       }
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i) {
@@ -375,9 +378,21 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   const Seg& s0 = a.seg[0];
   const bool lin = mfma && a.nseg == 1 && s0.ntaps == 1 && s0.taps[0] == 0 && s0.mode == G_PLAIN && s0.istride == 1 &&
                    s0.Hs == a.Ho && s0.Ws == a.Wo;
-  auto kern = !mfma ? igemm_kernel<T, BN, EPI, false, false> : (lin ? igemm_kernel<T, BN, EPI, true, true> : igemm_kernel<T, BN, EPI, true, false>);
-  const int ai = mfma ? (lin ? 2 : 1) : 0;
-  static int attr_bytes[3] = {0, 0, 0};
+  // prologue kind, identical for all segments of a launch: 0 none, 1 BN+ReLU, 2 effective gradient; pooled sources and
+  // mixed segments take the run-time variant
+  int pro = s0.scale ? 1 : (s0.q ? 2 : 0);
+  for (int s = 0; s < a.nseg; ++s) {
+    const Seg& sg = a.seg[s];
+    if (sg.mode == G_POOL2 || (sg.scale ? 1 : (sg.q ? 2 : 0)) != pro) pro = -1;
+  }
+  constexpr int P1 = EPI == EPI_BNBWD ? 2 : 1;  // the prologue this epilogue normally sees
+  void (*kern)(const ConvArgs);
+  int ai;
+  if (!mfma) { kern = igemm_kernel<T, BN, EPI, false, false, -1>; ai = 0; }
+  else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1> : igemm_kernel<T, BN, EPI, true, false, P1>; ai = lin ? 1 : 2; }
+  else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0> : igemm_kernel<T, BN, EPI, true, false, 0>; ai = lin ? 3 : 4; }
+  else { kern = igemm_kernel<T, BN, EPI, true, false, -1>; ai = 5; }
+  static int attr_bytes[6] = {0, 0, 0, 0, 0, 0};
   if (smem > 48 * 1024 && smem > attr_bytes[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

@@ -45,7 +45,10 @@ __device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
   return *(f16x4*)&r;
 }
 
-template <typename T, int WBN, bool MFMA>
+// PP / PQ = prologue kind of the pixel-aligned operand P and of the tapped operand Q (-1 run time, 0 none, 1 BN+ReLU,
+// 2 effective gradient); LIN = both operands are plain one-tap unit-stride tensors on the row grid (1x1 layers): the
+// source pixel is the row index, no row table and no coordinate arithmetic.
+template <typename T, int WBN, bool MFMA, int PP, int PQ, bool LIN>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
@@ -113,8 +116,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
 
   // issue-early / write-late (see igemm.hip): raw loads now, prologue when the tile is written to LDS one step later
   RawSlot<T> araw[LA], draw[LD];
+  int mt_next = mbeg;  // first row of the tile load_tiles() will fetch (LIN)
+  auto lin_issue = [&](const Seg& sg, RawSlot<T>& rs, int m, int c, bool cvalid, bool want2) {
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) { rs.v[e] = (T)0; rs.v2[e] = (T)0; }
+    rs.state = 0;
+    if (cvalid && m < mend) {
+      rs.v = *(const V*)((const T*)sg.src + (size_t)m * sg.ld + c);
+      if (want2) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)m * sg.ld2 + c);
+      rs.state = 1;
+    }
+  };
   auto load_tiles = [&](int which) {
     const Seg& sg = a.seg[ks];
+    if constexpr (LIN) {
+      const bool qv = ktap < sg.ntaps && kc < sg.C;
+#pragma unroll
+      for (int i = 0; i < LA; ++i) lin_issue(sg, araw[i], mt_next + rga + i * RGA, kc, qv, PQ == 2 || (PQ < 0 && sg.q != nullptr));
+#pragma unroll
+      for (int i = 0; i < LD; ++i) {
+        const int row = rgd + i * RGD;
+        lin_issue(a.dy, draw[i], mt_next + row, nD < a.N ? nD : 0, nD < a.N && row < BMW, PP == 2 || (PP < 0 && a.dy.q != nullptr));
+      }
+      mt_next += BMW;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int4 e = rowtab[which * BMW + rga + i * RGA];
@@ -131,11 +157,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   auto store_tiles = [&]() {
     const Seg& sg = a.seg[ks];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = gather_finish<T>(sg, araw[i], preQ);
+    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = gather_finish<T, PQ>(sg, araw[i], preQ);
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int row = rgd + i * RGD;
-      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = gather_finish<T>(a.dy, draw[i], preP);
+      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = gather_finish<T, PP>(a.dy, draw[i], preP);
     }
   };
 
@@ -150,14 +176,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   // transposed-read lane geometry (16-bit types): group g = lane>>4 covers columns 16*(g&1).., rows 8*(g>>1)..
   const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
 
-  fill_rowtab(0, mbeg);
+  if constexpr (!LIN) fill_rowtab(0, mbeg);
   __syncthreads();
   load_tiles(0);
   int which = 0;
   for (int mt = mbeg; mt < mend; mt += BMW) {
     store_tiles();
     const bool more = mt + BMW < mend;
-    if (more) fill_rowtab(which ^ 1, mt + BMW);
+    if constexpr (!LIN) { if (more) fill_rowtab(which ^ 1, mt + BMW); }
     __syncthreads();
     if (more) load_tiles(which ^ 1);
     if (MFMA) {
@@ -230,18 +256,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+static int seg_pro(const Seg& sg) { return sg.mode == G_POOL2 ? -1 : (sg.scale ? 1 : (sg.q ? 2 : 0)); }
+static bool seg_lin(const Seg& sg, const WgradArgs& a) {
+  return sg.ntaps == 1 && sg.taps[0] == 0 && sg.mode == G_PLAIN && sg.istride == 1 && sg.Hs == a.Ho && sg.Ws == a.Wo;
+}
+
 template <typename T, int WBN>
 static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
   typedef WgradSmem<T, WBN> SM;
   const int ntiles = a.Npad / WBN;
   const int splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
   dim3 grid(ntiles * a.kgroups * splits), block(NTHREADS);
-  auto kern = mfma ? wgrad_kernel<T, WBN, true> : wgrad_kernel<T, WBN, false>;
-  static bool attr_done[2] = {false, false};
-  if (SM::bytes > 48 * 1024 && !attr_done[mfma]) {
+  int pq = seg_pro(a.seg[0]);
+  for (int s = 1; s < a.nseg; ++s) if (seg_pro(a.seg[s]) != pq) pq = -1;
+  const int pp = seg_pro(a.dy);
+  const bool lin = a.nseg == 1 && seg_lin(a.seg[0], a) && seg_lin(a.dy, a);
+  void (*kern)(const WgradArgs);
+  int ai;
+  if (!mfma) { kern = wgrad_kernel<T, WBN, false, -1, -1, false>; ai = 0; }
+  else if (lin && pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, true>; ai = 1; }
+  else if (pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, false>; ai = 2; }
+  else if (pp == 1 && pq == 2) { kern = wgrad_kernel<T, WBN, true, 1, 2, false>; ai = 3; }
+  else if (pp == 2 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 2, 0, false>; ai = 4; }
+  else if (pp == 1 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 1, 0, false>; ai = 5; }
+  else { kern = wgrad_kernel<T, WBN, true, -1, -1, false>; ai = 6; }
+  static bool attr_done[7] = {false, false, false, false, false, false, false};
+  if (SM::bytes > 48 * 1024 && !attr_done[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
     if (e != hipSuccess) return e;
-    attr_done[mfma] = true;
+    attr_done[ai] = true;
   }
   hipLaunchKernelGGL(kern, grid, block, SM::bytes, st, a);
   return hipGetLastError();
