@@ -405,7 +405,8 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
 
 template <typename T, int EPI>
 static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
-  if (EPI == EPI_BNBWD) {  // float staging: keep the tile at 64 columns
+  if (EPI == EPI_BNBWD) {  // wide outputs take 128-column tiles: half as many re-gathers of the gradient operand
+    if (a.Npad % 128 == 0) return launch_bn<T, 128, EPI>(a, mfma, st);
     if (a.Npad % 64 == 0) return launch_bn<T, 64, EPI>(a, mfma, st);
     return launch_bn<T, 32, EPI>(a, mfma, st);
   }

@@ -400,7 +400,11 @@ struct Builder {
     }
     pd.st = 1;
     pd.w += base_off;
-    pd.Npad = dgrad_seg ? rup(c.seg[seg_index].C, c.seg[seg_index].C >= 64 ? 64 : 32) : rup(c.N, 32);
+    {
+      const int cs = dgrad_seg ? c.seg[seg_index].C : 0;
+      // data-gradient output width: 128-column tiles once the padding waste is <= 25 %, else 64, else 32
+      pd.Npad = dgrad_seg ? rup(cs, cs >= 384 || cs % 128 == 0 ? 128 : (cs >= 64 ? 64 : 32)) : rup(c.N, 32);
+    }
     int chunks = 0;
     for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
     const size_t elems = (size_t)chunks * pd.Npad * BK;
