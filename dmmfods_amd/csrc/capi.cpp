@@ -121,6 +121,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_POOLBWD: e = launch_maxpool_bwd(o.mpb, dt, st); break;
       case OP_BCE: e = launch_bce_metrics(o.bce, dt, st); break;
       case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, st); break;
+      case OP_APPLYCORR: e = launch_apply_corr(o.ac, dt, st); break;
       case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, st); break;
       default: return fail(DMM_ERR_STATE, "unknown op");
     }

@@ -256,6 +256,8 @@ struct Buf {
   double* qd = nullptr;   // ... and the fp64 accumulators they are split from
   double* rd = nullptr;
   bool ginit = false;
+  bool matz = false;          // single-consumer tensor whose gradient is re-gathered often: materialise q + r*x once
+  bool materialized = false;  // (set during backward emission) gradient already holds the effective gradient
 };
 
 struct BnRange { int buf, ch0, c0, n; double count, count_unb; bool want_qr; };
@@ -333,8 +335,9 @@ struct Builder {
     return *it->second;
   }
 
-  int new_buf(int B, int H, int W_, int cw, bool grad, bool stats) {
+  int new_buf(int B, int H, int W_, int cw, bool grad, bool stats, bool matz = false) {
     Buf b;
+    b.matz = matz && getenv("DMM_NO_MATZ") == nullptr;
     // Pixel pitch: power-of-two pitches make every workgroup hit the same HBM channels at the same time (all of them read
     // the same 64-byte column window of their rows as they walk K in step), so wide buffers get an odd multiple of 64 B.
     int ld = cw;
@@ -540,7 +543,7 @@ struct Builder {
     s.C = C; s.Cpad = C;
     s.mode = G_PLAIN;
     s.istride = istride;
-    if (b.q) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; s.ql = b.ql + ch0; s.rl = b.rl + ch0; }
+    if (b.q && !b.materialized) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; s.ql = b.ql + ch0; s.rl = b.rl + ch0; }
     fill_seg_taps(s, taps, BK);
   }
 
@@ -560,6 +563,18 @@ struct Builder {
       a.count = rg.count;
       a.grad_scale = 1.0f / d.loss_scale;
       a.C = rg.n;
+    }
+    for (auto& rg : b.ranges) {
+      Buf& sb = bufs[rg.buf];
+      if (!(rg.want_qr && sb.q && sb.matz) || sb.materialized) continue;
+      Op& o = push(OP_APPLYCORR);
+      ApplyCorrArgs& a = o.ac;
+      a.g = gat(rg.buf, rg.ch0); a.y = xat(rg.buf, rg.ch0);
+      a.q = sb.q + rg.ch0; a.r = sb.r + rg.ch0; a.ql = sb.ql + rg.ch0; a.rl = sb.rl + rg.ch0;
+      a.npix = (size_t)sb.B * sb.H * sb.W;
+      a.C = rup(rg.n, 8); a.ldg = sb.ld; a.ldy = sb.ld;
+      tag(o, "applycorr", "grad", 0, 3.0 * a.npix * a.C * esz);
+      sb.materialized = true;
     }
   }
 
@@ -584,7 +599,7 @@ struct Builder {
       a.dpack = (float*)pd.dpack;
       char cb[32];
       tag(o, ncls("wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
-          src_bytes(c) + (ob.q ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
+          src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
     } else
     for (auto& ph : c.phases) {
       Op& o = push(OP_WGRAD);
@@ -603,7 +618,7 @@ struct Builder {
         const double np = (double)c.phases.size();
         // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
         tag(o, ncls("wgrad", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
-            (src_bytes(c) + (ob.q ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
+            (src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
     // ---- data gradients with fused BN+ReLU backward ----
@@ -645,7 +660,7 @@ struct Builder {
         const double srcb = (double)sb.B * sb.H * sb.W * sr.C * esz;
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
         tag(o, ncls("igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
-            (ob.q ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
+            ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
       sb.ginit = true;
     }
@@ -764,7 +779,7 @@ struct Builder {
     for (int l = 0; l < g.L[b]; ++l) {
       const std::string q = p + ".denselayer" + std::to_string(l + 1);
       const int K = g.cin[b] + l * g.k;
-      const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true);
+      const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true, /*matz=*/K >= 384);
       const int n1 = new_bn(q + ".norm1", K);
       bn_range(n1, xb, base, 0, K);
       {
@@ -861,7 +876,7 @@ struct Builder {
       if (I.cw != nin) throw std::runtime_error("decoder width mismatch");
       const int n0 = new_bn(p + ".norm0", nin);
       bn_range(n0, inb, 0, 0, nin);
-      const int Rb = new_buf(I.B, I.H, I.W, nf, true, true);
+      const int Rb = new_buf(I.B, I.H, I.W, nf, true, true, /*matz=*/true);
       {
         ConvRec& c = new_conv(p + ".conv_reduce.weight", false, nf, nin, 1, 1, 0);
         set_seg(c, 0, inb, 0, nin, 0, G_PLAIN, 1, n0, 0, DG_FLIP);
@@ -873,7 +888,7 @@ struct Builder {
       bn_range(n1, Rb, 0, 0, nf);
       int ob;
       if (j < g.nb - 1) ob = X[g.nb - 2 - j];
-      else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true);
+      else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true, /*matz=*/true);
       if (bufs[ob].H != 2 * I.H) throw std::runtime_error("decoder size mismatch");
       {
         ConvRec& c = new_conv("decoder.Transposed_Convolution_" + std::to_string(j + 1) + ".weight", true, nf, nf, 3, 3, 1);
@@ -889,7 +904,7 @@ struct Builder {
     const int hn0 = new_bn("dec_out_to_heat_maps.norm0", nfl + raw);
     bn_range(hn0, U, 0, 0, nfl, 4.0);
     bn_range(hn0, inH, 0, nfl, raw, 1.0, false);
-    const int YR = new_buf(B, H, Wd, nfl / 2, true, true);
+    const int YR = new_buf(B, H, Wd, nfl / 2, true, true, /*matz=*/true);
     {
       ConvRec& c = new_conv("dec_out_to_heat_maps.refine0.weight", false, nfl / 2, nfl + raw, 3, 3, 1);
       // The decoder part of the input is a nearest-x2 upsample, so the conv is evaluated per output parity (e,f) on the
@@ -1010,7 +1025,7 @@ struct Builder {
       P.bce_only = o;
       P.bce_only.bce.dlogits = nullptr;
     }
-    for (auto& b : bufs) b.ginit = false;
+    for (auto& b : bufs) { b.ginit = false; b.materialized = false; }
     for (int i = (int)recs.size() - 1; i >= 0; --i) {
       if (recs[i].type == 0) emit_conv_bwd(convs[recs[i].idx]); else emit_pool_bwd(pools[recs[i].idx]);
     }

@@ -93,6 +93,17 @@ struct BceArgs {
   float thr, loss_scale;
 };
 
+struct ApplyCorrArgs {
+  void* g;        // T gradient, pixel stride ldg: g += (q + ql) + (r + rl) * y
+  const void* y;  // T forward tensor, pixel stride ldy
+  const float* q;
+  const float* r;
+  const float* ql;
+  const float* rl;
+  size_t npix;
+  int C, ldg, ldy;
+};
+
 struct AdamArgs {
   float* p;
   const float* g;
@@ -127,6 +138,7 @@ hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st);
 hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st);
 hipError_t launch_bce_metrics(const BceArgs& a, int dtype, hipStream_t st);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st);
 hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st);
 hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
                          hipStream_t st);

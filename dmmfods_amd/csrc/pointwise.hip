@@ -385,6 +385,39 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Materialise the deferred BatchNorm-backward correction of a gradient tensor that will be gathered many times
+// (several taps / output tiles / K groups): afterwards its consumers read a plain tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void apply_corr_kernel(ApplyCorrArgs a) {
+  constexpr int SLOT = TT<T>::SLOT;
+  typedef typename TT<T>::vec V;
+  const int ncs = a.C / SLOT;
+  const size_t total = a.npix * ncs;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / ncs;
+    const int c = (int)(i - p * ncs) * SLOT;
+    T* gp = (T*)a.g + p * a.ldg + c;
+    float f[SLOT], y[SLOT], q[SLOT], r[SLOT], ql[SLOT], rl[SLOT];
+    vec_to_f32<T>(*(const V*)gp, f);
+    vec_to_f32<T>(*(const V*)((const T*)a.y + p * a.ldy + c), y);
+    load_f32s<SLOT>(a.q + c, q); load_f32s<SLOT>(a.r + c, r); load_f32s<SLOT>(a.ql + c, ql); load_f32s<SLOT>(a.rl + c, rl);
+#pragma unroll
+    for (int k = 0; k < SLOT; ++k) f[k] = (f[k] + fmaf(r[k], y[k], q[k])) + fmaf(rl[k], y[k], ql[k]);
+    *(V*)gp = f32_to_vec<T>(f);
+  }
+}
+
+hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st) {
+  const size_t total = a.npix * (a.C / (dtype == DT_F16 ? 8 : 4));
+  int grid = (int)((total + 255) / 256);
+  if (grid > 16384) grid = 16384;
+  if (grid < 1) return hipSuccess;
+  if (dtype == DT_F16) hipLaunchKernelGGL(apply_corr_kernel<f16>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(apply_corr_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // pack: one thread per (chunk, n) row of BK elements.  unpack: the same enumeration run backwards.
 __device__ __forceinline__ bool pack_locate(const PackDesc& d, int chunk, int kk, int BK, int& seg, int& tap, int& ch) {
   int s = 0, lc = chunk;

@@ -275,12 +275,14 @@ static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
   int ai;
   if (!mfma) { kern = wgrad_kernel<T, WBN, false, -1, -1, false>; ai = 0; }
   else if (lin && pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, true>; ai = 1; }
+  else if (lin && pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, true>; ai = 7; }
+  else if (pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, false>; ai = 8; }
   else if (pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, false>; ai = 2; }
   else if (pp == 1 && pq == 2) { kern = wgrad_kernel<T, WBN, true, 1, 2, false>; ai = 3; }
   else if (pp == 2 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 2, 0, false>; ai = 4; }
   else if (pp == 1 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 1, 0, false>; ai = 5; }
   else { kern = wgrad_kernel<T, WBN, true, -1, -1, false>; ai = 6; }
-  static bool attr_done[7] = {false, false, false, false, false, false, false};
+  static bool attr_done[9] = {false, false, false, false, false, false, false, false, false};
   if (SM::bytes > 48 * 1024 && !attr_done[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
     if (e != hipSuccess) return e;
