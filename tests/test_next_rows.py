@@ -1,0 +1,106 @@
+"""dataset reader for the reference's batched .pt format, focal losses, agent counterpart."""
+import os
+
+import pytest
+import torch
+
+from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+
+
+def _cfg(tmp_path):
+    cfg = get_config(str(tmp_path))
+    cfg.dir.data.root = str(tmp_path / "data")
+    cfg.dir.data.file_lists = str(tmp_path / "lists")
+    cfg.dir.current_run.summary = str(tmp_path / "run" / "summary")
+    cfg.dir.current_run.checkpoints = str(tmp_path / "run" / "checkpoints")
+    cfg.loader.num_workers = 0
+    cfg.loader.pin_memory = False
+    return cfg
+
+
+def _write_batches(cfg, nfiles=2, n=2, h=64, w=96):
+    g = torch.Generator().manual_seed(0)
+    for mode in ("train", "val"):
+        d = os.path.join(cfg.dir.data.root, mode, "part0")
+        os.makedirs(os.path.join(d, "labels"), exist_ok=True)
+        for i in range(nfiles):
+            t = torch.rand(n, 7, h, w, generator=g)
+            t[:, :4] *= 255
+            t[:, 4:] = (t[:, 4:] > 0.9).float()
+            torch.save(t, os.path.join(d, f"batch_{i}.pt"))
+
+
+def test_dataset_reads_reference_batched_format(tmp_path):
+    from dmmfods_amd.datasets.WaymoData import WaymoDataset, WaymoDataset_Loader
+    cfg = _cfg(tmp_path)
+    _write_batches(cfg)
+    ds = WaymoDataset("train", cfg)
+    assert len(ds) == 2 and ds.data_is_batched
+    rgb, lidar, heat = ds[0]
+    assert rgb.shape == (2, 3, 64, 96) and lidar.shape == (2, 1, 64, 96) and heat.shape == (2, 3, 64, 96)
+    assert os.path.isfile(os.path.join(cfg.dir.data.file_lists, "train_file_list.json"))
+    ds2 = WaymoDataset("train", cfg)          # second construction goes through the JSON cache
+    assert ds2.files == ds.files
+    ld = WaymoDataset_Loader(cfg)
+    assert ld.train_iterations == 2 and ld.valid_iterations == 2
+    b = next(iter(ld.train_loader))
+    assert b[0].shape == (2, 3, 64, 96)
+    cfg.loader.batch_size = 4
+    os.remove(os.path.join(cfg.dir.data.file_lists, "train_file_list.json"))
+    with pytest.raises(ValueError):
+        WaymoDataset("train", cfg)
+    with pytest.raises(ValueError):
+        WaymoDataset("bogus", cfg)
+
+
+def test_focal_losses_match_definition():
+    from dmmfods_amd.graphs.losses.FocalLoss import ClassWiseFocalLoss, FocalLoss
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 5, 7, generator=g)
+    t = (torch.rand(2, 3, 5, 7, generator=g) > 0.8).float()
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
+    want = 0.5 * (1 - torch.exp(-bce)) ** 2 * bce
+    torch.testing.assert_close(FocalLoss(alpha=0.5, gamma=2, logits=True, reduce=False)(x, t), want)
+    torch.testing.assert_close(FocalLoss(alpha=0.5, gamma=2, logits=True, reduce=True)(x, t), want.mean())
+    alpha, gamma = [1.0, 2.0, 0.5], [2.0, 1.0, 3.0]
+    cw = ClassWiseFocalLoss(alpha, gamma)(x, t)
+    for c in range(3):
+        torch.testing.assert_close(cw[:, c], alpha[c] * (1 - torch.exp(-bce[:, c])) ** gamma[c] * bce[:, c])
+    p = torch.sigmoid(x)
+    torch.testing.assert_close(FocalLoss(1, 2, logits=False, reduce=False)(p, t), (1 - torch.exp(-bce)) ** 2 * bce, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_agent_trains_validates_and_resumes(tmp_path):
+    from dmmfods_amd.agents.Dense_U_Net_lidar_Agent import Dense_U_Net_lidar_Agent
+    cfg = _cfg(tmp_path)
+    _write_batches(cfg)
+    cfg.agent.max_epoch = 2
+    cfg.optimizer.lr_scheduler.want = True
+    cfg.optimizer.lr_scheduler.every_n_epochs = 1
+    agent = Dense_U_Net_lidar_Agent(cfg)
+    assert agent.model.fusion == "mid"                    # reference defaults: concat before block 2, 1 LiDAR channel
+    w0 = agent.model.param_arena.clone()
+    agent.run()
+    agent.finalize()
+    assert agent.current_train_iteration == 4 and agent.current_val_iteration == 4
+    assert not torch.equal(w0, agent.model.param_arena)
+    assert abs(agent.optimizer.param_groups[0]["lr"] - 1e-3 * 0.1 ** 2) < 1e-12
+    ck_dir = cfg.dir.current_run.checkpoints
+    assert os.path.isfile(os.path.join(ck_dir, "checkpoint.pth.tar"))
+    ck = torch.load(os.path.join(ck_dir, "checkpoint.pth.tar"), map_location="cpu")
+    assert set(ck) == {"epoch", "train_iteration", "val_iteration", "best_val_iou", "state_dict", "optimizer"}
+    # resume: a fresh agent restores weights, counters and Adam state from the checkpoint
+    os.replace(os.path.join(ck_dir, "checkpoint.pth.tar"), os.path.join(ck_dir, cfg.agent.best_checkpoint_name))
+    agent2 = Dense_U_Net_lidar_Agent(cfg, torchvision_init=False)
+    assert agent2.current_train_iteration == 4
+    torch.testing.assert_close(agent2.model.param_arena.cpu(), agent.model.param_arena.cpu())
+    assert agent2.optimizer.step_count == 4
+    torch.testing.assert_close(agent2.optimizer.exp_avg.cpu(), agent.optimizer.exp_avg.cpu())
+    # focal loss through the autograd bridge (reference L:52-91 as an alternative loss)
+    from dmmfods_amd.graphs.losses.FocalLoss import ClassWiseFocalLoss
+    image, lidar, ht = next(iter(agent.data_loader.train_loader))
+    agent.model.train()
+    pred = agent.model(image.cuda(), lidar.cuda())
+    ClassWiseFocalLoss()(pred, ht.cuda()).sum().backward()
+    assert torch.isfinite(agent.model.grad_arena).all() and float(agent.model.grad_arena.abs().max()) > 0
