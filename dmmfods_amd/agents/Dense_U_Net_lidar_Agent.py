@@ -61,8 +61,9 @@ class Dense_U_Net_lidar_Agent:
         o = self.config.optimizer
         self.optimizer = FusedAdam(self.model, lr=o.learning_rate, betas=(o.beta1, o.beta2), eps=o.eps,
                                    weight_decay=o.weight_decay, amsgrad=o.amsgrad)
-        self.lr_scheduler = _StepLR(self.optimizer, o.lr_scheduler.every_n_epochs, o.lr_scheduler.gamma) \\
-            if o.lr_scheduler.want else None
+        self.lr_scheduler = None
+        if o.lr_scheduler.want:
+            self.lr_scheduler = _StepLR(self.optimizer, o.lr_scheduler.every_n_epochs, o.lr_scheduler.gamma)
         self.current_epoch = self.current_train_iteration = self.current_val_iteration = 0
         self.best_val_iou = 0
         self.cuda = torch.cuda.is_available()

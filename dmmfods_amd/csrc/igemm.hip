@@ -44,7 +44,7 @@ struct IgemmSmem {
   static constexpr int MAIN = 2 * (A_BYTES + B_BYTES);
   static constexpr int STAGE_T = BM * STAGE_PITCH_T * (int)sizeof(T);
   static constexpr int STAGE_F = BM * STAGE_PITCH_F * 4;
-  static constexpr int EXTRA = BM * 4 + 2 * BN * 8;  // rowpix + fp64 reduction scratch
+  static constexpr int EXTRA = BM * 4 + 2 * BN * 8 + BM * 16;  // rowpix + fp64 reduction scratch + row coordinates
   static constexpr int bytes(int epi) {  // without the per-launch prologue-constant image
     int st = (epi == EPI_STORE) ? STAGE_T : STAGE_F;
     int m = MAIN > st ? MAIN : st;
@@ -55,6 +55,70 @@ struct IgemmSmem {
 // LIN = lean path for plain 1x1 convolutions (one segment, one tap, unit stride, same grid): the source pixel of a row
 // is the row itself, so the K loop needs no tap walker, coordinates or bounds tests.
 // PRO = prologue of every segment, fixed at compile time for the MFMA variants (-1: look at the segment at run time).
+//
+// Operand staging per pipeline stage (KS = 2 chunks of 64 bytes of K):
+//   A (gathered activations): waves 0-1 stage chunk 0, waves 2-3 chunk 1.  A thread owns ONE slot column j and FOUR rows
+//     (rg + 32 i), so the chunk-level work (K-table entry, prologue constants) is shared by four slots.  The loads are
+//     issued right after the barrier and consumed (prologue + ds_write) one iteration later, behind the MFMAs.
+//   B (packed weights): never touches registers - global_load_lds_dwordx4 writes the tile image directly; the XOR
+//     swizzle of the image is applied on the per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear).
+//   K walk: a table in LDS, built once per workgroup, maps (chunk, j) -> segment, tap offset and channel, so the loop
+//     has no divisions, tap-table loads or walker state.
+struct SegU {  // the wave-uniform part of a Seg that the K loop needs (lives in SGPRs)
+  const void* src;
+  const void* src2;
+  int ld, ld2, Hs, Ws, istride, mode, C, narr;
+};
+__device__ __forceinline__ SegU seg_uniform(const Seg& sg) {
+  SegU r;
+  r.src = sg.src; r.src2 = sg.src2; r.ld = sg.ld; r.ld2 = sg.ld2; r.Hs = sg.Hs; r.Ws = sg.Ws;
+  r.istride = sg.istride; r.mode = sg.mode; r.C = sg.C; r.narr = sg.scale ? 2 : (sg.q ? 4 : 0);
+  return r;
+}
+
+// BN+ReLU on one 16-byte slot of f16: v_fma_mixlo/mixhi_f16 take the f16 half as an fp32 operand and round the fp32 fma
+// once to f16 (identical to (f16)fmaf((float)x, s, t)); ReLU commutes with that rounding and runs packed.
+__device__ __forceinline__ f16x8 bn_relu_slot(const f16x8& x, const SlotK<8>& k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xi = __builtin_bit_cast(u32x4, x);
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xi[p]), "v"(k.k0[2 * p]), "v"(k.k1[2 * p]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(d) : "v"(xi[p]), "v"(k.k0[2 * p + 1]), "v"(k.k1[2 * p + 1]));
+    o[p] = d;
+  }
+  const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_elementwise_max(__builtin_bit_cast(f16x8, o), z);
+}
+__device__ __forceinline__ f32x4 bn_relu_slot(const f32x4& x, const SlotK<4>& k) {
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(x[i], k.k0[i], k.k1[i]), 0.f);
+  return o;
+}
+
+// narr: 0 = no prologue, 2 = BN+ReLU, 4 = effective gradient (run-time value used by PRO < 0 only)
+template <typename T, int PRO>
+__device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {
+  constexpr int S = TT<T>::SLOT;
+  typename TT<T>::vec out = r.v;
+  const bool bn = PRO == 1 || (PRO < 0 && narr == 2);
+  const bool eg = PRO == 2 || (PRO < 0 && narr == 4);
+  if (PRO == 1 || (PRO < 0 && bn)) out = bn_relu_slot(r.v, k);
+  if (PRO == 2 || (PRO < 0 && eg)) {
+    float f[S], f2[S];
+    vec_to_f32<T>(r.v, f);
+    vec_to_f32<T>(r.v2, f2);
+#pragma unroll
+    for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
+    out = f32_to_vec<T>(f);
+  }
+  return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
+}
+
 template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
@@ -62,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   typedef typename TT<T>::vec V;
   typedef IgemmSmem<T, BN> SM;
   constexpr int NT = BN / 32;
-  constexpr int BSLOTS = (BN * 4 + NTHREADS - 1) / NTHREADS;  // B slots per thread per chunk
+  constexpr int NB = BN / 32;  // 1-KiB LDS-DMA pieces of the B image per wave per stage
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAINB = (SM::MAIN > (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F)) ? SM::MAIN
@@ -72,6 +136,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   // the gradient, and an error of 1e-7*sum|dz| in that mean is a coherent offset that the next weight-gradient GEMM
   // amplifies over all pixels (torch's CPU BatchNorm accumulates in double for the same reason).
   double* red = (double*)(smem + MAINB + BM * 4);
+  int4* rowinfo = (int4*)(smem + MAINB + BM * 4 + 2 * BN * 8);  // (b, y, x, valid) of every tile row
   // prologue constants (scale/shift or q/r/q_lo/r_lo) of every segment, staged once: the gather then issues ONE vector
   // memory instruction per slot instead of five (the L1-hit constant loads were saturating the texture-address path)
   float* lk0 = (float*)(smem + MAINB + SM::EXTRA);
@@ -82,31 +147,63 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
 
-  // ---- per-thread A rows (two rows, one slot column) ----
-  const int j = tid & 3;
-  const int ar0 = tid >> 2;
-  int rb[2], ry[2], rx[2];
-  bool rv[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + ar0 + 64 * i;
-    rv[i] = m < a.M;
-    row_to_byx(rv[i] ? m : 0, a.Ho, a.Wo, rb[i], ry[i], rx[i]);
-  }
+  const int u = tid >> 7;          // chunk of the stage this thread gathers (wave-uniform)
+  const int j = tid & 3;           // slot column
+  const int rg = (tid >> 2) & 31;  // rows rg + 32 i
+
   if (tid < BM) {
     const int m = m0 + tid;
     int pb, py_, px_;
     row_to_byx(m < a.M ? m : 0, a.Ho, a.Wo, pb, py_, px_);
     rowpix[tid] = m < a.M ? (pb * a.Hout + py_ * a.ostride + a.py) * a.Wout + px_ * a.ostride + a.px : -1;
+    rowinfo[tid] = make_int4(pb, py_, px_, m < a.M ? 1 : 0);
   }
   if (tid < 2 * BN) red[tid] = 0.0;
   const int nk0 = stage_consts(a.seg[0], lk0, tid, NTHREADS);
   float* lk1 = lk0 + nk0;
-  if (a.nseg > 1) stage_consts(a.seg[1], lk1, tid, NTHREADS);
+  int nk1 = 0;
+  if (a.nseg > 1) nk1 = stage_consts(a.seg[1], lk1, tid, NTHREADS);
+
+  const int nch0 = a.seg[0].nchunks;
+  const int total = nch0 + (a.nseg > 1 ? a.seg[1].nchunks : 0);
+
+  // K table: bit 0 segment, bit 1 slot is inside the enumeration, bits 2-9 dy, 10-17 dx (signed), 18.. channel
+  int* ktab = (int*)(lk1 + nk1);
+  if constexpr (!LIN) {
+    for (int e = tid; e < total * 4; e += NTHREADS) {
+      const int g = e >> 2, jj = e & 3;
+      const int s = g >= nch0 ? 1 : 0;
+      const Seg& sg = a.seg[s];
+      const int k = (g - (s ? nch0 : 0)) * BK + jj * SLOT;
+      const int tap = k / sg.Cpad, c = k - tap * sg.Cpad;
+      int ent = s;
+      if (tap < sg.ntaps && c < sg.C) {
+        const int t = sg.taps[tap];
+        ent |= 2 | ((t & 0xff) << 2) | (((t >> 8) & 0xff) << 10) | (c << 18);
+      }
+      ktab[e] = ent;
+    }
+  }
   __syncthreads();
 
-  int total = 0;
-  for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
+  const SegU su0 = seg_uniform(a.seg[0]);
+  const SegU su1 = seg_uniform(a.seg[a.nseg > 1 ? 1 : 0]);
+
+  int rb[4], ry[4], rx[4];
+  bool rv[4];
+  size_t roff[4], roff2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (LIN) {
+      const int m = m0 + rg + 32 * i;
+      rv[i] = m < a.M;
+      roff[i] = (size_t)(rv[i] ? m : 0) * su0.ld;
+      roff2[i] = (size_t)(rv[i] ? m : 0) * su0.ld2;
+    } else {
+      const int4 ri = rowinfo[rg + 32 * i];
+      rb[i] = ri.x; ry[i] = ri.y; rx[i] = ri.z; rv[i] = ri.w != 0;
+    }
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -114,118 +211,119 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  KWalk kw;
-  kw_enter<SLOT>(kw, a.seg, 0, j);
+  // B: per-lane source offsets of this wave's LDS-DMA pieces (fixed over K)
   const T* wp = (const T*)a.wpack;
+  int boff[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int nn = ((wave & 1) * NB + q) * 16 + (lane >> 2);
+    const int sl = (lane & 3) ^ ((nn >> 2) & 3);
+    boff[q] = (n0 + nn) * BK + sl * SLOT;
+  }
 
-  // issue-early / write-late: load_chunk only issues the global loads of the next K-step; the prologue (BN+ReLU or the
-  // deferred-gradient correction) runs in store_chunk one iteration later, after that step's MFMAs.
-  RawSlot<T> araw[KS][2];
-  V breg[KS][BSLOTS];
-  int sv_s[KS], sv_c[KS], sv_narr[KS];
-  int gnext = 0;  // next global chunk to issue
-  auto load_stage = [&]() {
+  // issue-early / write-late: load_stage only issues the global loads of the next K-step; the prologue (BN+ReLU or the
+  // deferred-gradient correction) runs in store_stage one iteration later, after that step's MFMAs.
+  RawSlot<T> araw[4];
+  int sv_s = 0, sv_c = 0, sv_narr = 0;
+  int gnext = 0;  // first chunk of the next stage to issue
+  auto load_stage = [&](int buf) {
+    const int g = gnext + u;
+    gnext += KS;
+    const bool live = g < total;
+    {  // weights: LDS-DMA (a dead chunk re-reads chunk 0: its A slots are zero)
+      const T* bsrc = wp + (size_t)(live ? g : 0) * a.Npad * BK;
+      unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + u * BN * ROWB + (wave & 1) * NB * 1024;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {
-      const int gchunk = gnext++;
-      const bool live = gchunk < total;
-      if constexpr (LIN) {
-        const Seg& sg = a.seg[0];
-        const int c = gchunk * BK + j * SLOT;
-        const bool cv = live && c < sg.C;
-        sv_s[u] = 0; sv_c[u] = c; sv_narr[u] = cv ? (sg.scale ? 2 : (sg.q ? 4 : 0)) : 0;
+      for (int q = 0; q < NB; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff[q]),
+                                         (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          RawSlot<T>& rs = araw[u][i];
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-          for (int e = 0; e < SLOT; ++e) { rs.v[e] = (T)0; rs.v2[e] = (T)0; }
-          rs.state = 0;
-          if (cv && rv[i]) {
-            const size_t off = (size_t)(m0 + ar0 + 64 * i) * sg.ld + c;
-            rs.v = *(const V*)((const T*)sg.src + off);
-            if (PRO == 2 || (PRO < 0 && sg.q != nullptr)) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)(m0 + ar0 + 64 * i) * sg.ld2 + c);
-            rs.state = 1;
-          }
-        }
+      for (int e = 0; e < SLOT; ++e) { araw[i].v[e] = (T)0; araw[i].v2[e] = (T)0; }
+      araw[i].state = 0;
+    }
+    if constexpr (LIN) {
+      const int c = g * BK + j * SLOT;
+      const bool cv = live && c < su0.C;
+      sv_s = 0; sv_c = c; sv_narr = cv ? su0.narr : 0;
 #pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) {
-          const int q = tid + i * NTHREADS;
-          if (q < BN * 4) {
-            const int n = q >> 2, jj = q & 3;
-            V z;
-#pragma unroll
-            for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
-            breg[u][i] = live ? *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT) : z;
-          }
-        }
-        continue;
-      }
-      const Seg& sg = a.seg[live ? kw.s : 0];
-      const int narr = sg.scale ? 2 : (sg.q ? 4 : 0);
-      sv_s[u] = live ? kw.s : 0; sv_c[u] = kw.c; sv_narr[u] = (live && kw.tap < sg.ntaps) ? narr : 0;
-      SlotK<SLOT> kpool;
-      if (sg.mode == G_POOL2) kpool = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], kw.c);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) araw[u][i] = gather_issue<T>(sg, rb[i], ry[i], rx[i], rv[i] && live, kw.tap, kw.c, kpool);
-#pragma unroll
-      for (int i = 0; i < BSLOTS; ++i) {
-        const int q = tid + i * NTHREADS;
-        if (q < BN * 4) {
-          const int n = q >> 2, jj = q & 3;
-          V z;
-#pragma unroll
-          for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
-          breg[u][i] = live ? *(const V*)(wp + ((size_t)gchunk * a.Npad + n0 + n) * BK + jj * SLOT) : z;
+      for (int i = 0; i < 4; ++i) {
+        if (cv && rv[i]) {
+          araw[i].v = *(const V*)((const T*)su0.src + roff[i] + c);
+          if (PRO == 2 || (PRO < 0 && su0.narr == 4)) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + c);
+          araw[i].state = 1;
         }
       }
-      if (live && gchunk + 1 < total) kw_next<SLOT>(kw, a.seg, a.nseg, j);
+      return;
+    }
+    const int ent = live ? ktab[g * 4 + j] : 0;
+    const bool s1 = (__builtin_amdgcn_readfirstlane(ent) & 1) != 0;  // the segment is chunk- (hence wave-) uniform
+    const SegU& su = s1 ? su1 : su0;
+    const bool inside = (ent & 2) != 0;
+    const int dy = (ent << 22) >> 24, dx = (ent << 14) >> 24, c = (int)((unsigned)ent >> 18);
+    sv_s = s1 ? 1 : 0; sv_c = c; sv_narr = inside ? su.narr : 0;
+    if (su.mode == G_POOL2) {  // four loads + averaging: rare (transitions), done synchronously
+      const Seg& sg = a.seg[sv_s];
+      const SlotK<SLOT> kpool = lds_slot_consts<SLOT>(s1 ? lk1 : lk0, su.C, sv_narr, c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (inside && rv[i]) {
+          araw[i].v = gather_slot<T, true>(sg, rb[i], ry[i], rx[i], true, 0, c, kpool);
+          araw[i].state = 2;
+        }
+      }
+      return;
+    }
+    const int up = su.mode == G_UP2 ? 1 : 0;
+    const unsigned hl = (unsigned)su.Hs << up, wl = (unsigned)su.Ws << up;
+    const bool two = PRO == 2 || (PRO < 0 && su.narr == 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sy = ry[i] * su.istride + dy, sx = rx[i] * su.istride + dx;
+      if (inside && rv[i] && (unsigned)sy < hl && (unsigned)sx < wl) {
+        const size_t pix = (size_t)((rb[i] * su.Hs + (sy >> up)) * su.Ws + (sx >> up));
+        araw[i].v = *(const V*)((const T*)su.src + pix * su.ld + c);
+        if (two) araw[i].v2 = *(const V*)((const T*)su.src2 + pix * su.ld2 + c);
+        araw[i].state = 1;
+      }
     }
   };
   auto store_stage = [&](int buf) {
     unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
-    unsigned char* Bs = As + SM::A_BYTES;
+    const float* lk = sv_s ? lk1 : lk0;
+    const int cst = sv_s ? su1.C : su0.C;
+    SlotK<SLOT> kk;
+    if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(lk, cst, sv_c);
+    else kk = lds_slot_consts<SLOT>(lk, cst, sv_narr, sv_c);
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {
-      const Seg& sg = a.seg[sv_s[u]];
-      SlotK<SLOT> kk;
-      if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(sv_s[u] ? lk1 : lk0, sg.C, sv_c[u]);
-      else kk = lds_slot_consts<SLOT>(sv_s[u] ? lk1 : lk0, sg.C, sv_narr[u], sv_c[u]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = u * BM + ar0 + 64 * i;
-        *(V*)(As + row * ROWB + ((j ^ ((row >> 2) & 3)) << 4)) = gather_finish<T, PRO>(sg, araw[u][i], kk);
-      }
-#pragma unroll
-      for (int i = 0; i < BSLOTS; ++i) {
-        const int q = tid + i * NTHREADS;
-        if (q < BN * 4) {
-          const int row = u * BN + (q >> 2);
-          *(V*)(Bs + row * ROWB + (((q & 3) ^ ((row >> 2) & 3)) << 4)) = breg[u][i];
-        }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int row = u * BM + rg + 32 * i;
+      *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = finish_slot<T, PRO>(sv_narr, araw[i], kk);
     }
   };
 
   const int r = lane & 31, h = lane >> 5;
   const int nstages = (total + KS - 1) / KS;
-  load_stage();
+  load_stage(0);
   for (int it = 0; it < nstages; ++it) {
     const int buf = it & 1;
     store_stage(buf);
-    __syncthreads();
-    if (it + 1 < nstages) load_stage();
+    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+    if (it + 1 < nstages) load_stage(buf ^ 1);
     const unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
     const unsigned char* Bs = As + SM::A_BYTES;
     if (MFMA) {
 #pragma unroll
-      for (int u = 0; u < KS; ++u)
+      for (int uu = 0; uu < KS; ++uu)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int sw = ((2 * s + h) ^ ((r >> 2) & 3)) << 4;  // BM, BN and 32 are multiples of 16: swizzle depends on r only
-          const V av = *(const V*)(As + (u * BM + 32 * wave + r) * ROWB + sw);
+          const V av = *(const V*)(As + (uu * BM + 32 * wave + r) * ROWB + sw);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const V bv = *(const V*)(Bs + (u * BN + 32 * t + r) * ROWB + sw);
+            const V bv = *(const V*)(Bs + (uu * BN + 32 * t + r) * ROWB + sw);
             Mma<T>::run(acc[t], av, bv);
           }
         }
@@ -237,9 +335,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
         for (int i = 0; i < 16; ++i) {
           const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
           float s = 0.f;
-          for (int u = 0; u < KS; ++u) {
-            const T* ap = (const T*)(As + (u * BM + row) * ROWB);
-            const T* bp = (const T*)(Bs + (u * BN + 32 * t + r) * ROWB);
+          for (int uu = 0; uu < KS; ++uu) {
+            const T* ap = (const T*)(As + (uu * BM + row) * ROWB);
+            const T* bp = (const T*)(Bs + (uu * BN + 32 * t + r) * ROWB);
             for (int k = 0; k < BK; ++k) {
               const int ka = (((k / SLOT) ^ ((row >> 2) & 3)) * SLOT) + k % SLOT;
               const int kb = (((k / SLOT) ^ ((r >> 2) & 3)) * SLOT) + k % SLOT;
@@ -374,7 +472,9 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   dim3 grid(mtiles * ntiles), block(NTHREADS);
   int kfl = 0;
   for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
-  const int smem = IgemmSmem<T, BN>::bytes(EPI) + kfl * 4 + 16;
+  int nchunks = 0;
+  for (int s = 0; s < a.nseg; ++s) nchunks += a.seg[s].nchunks;
+  const int smem = IgemmSmem<T, BN>::bytes(EPI) + kfl * 4 + nchunks * 16 + 16;
   const Seg& s0 = a.seg[0];
   const bool lin = mfma && a.nseg == 1 && s0.ntaps == 1 && s0.taps[0] == 0 && s0.mode == G_PLAIN && s0.istride == 1 &&
                    s0.Hs == a.Ho && s0.Ws == a.Wo;

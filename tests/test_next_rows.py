@@ -70,6 +70,23 @@ def test_focal_losses_match_definition():
     torch.testing.assert_close(FocalLoss(1, 2, logits=False, reduce=False)(p, t), (1 - torch.exp(-bce)) ** 2 * bce, rtol=1e-4, atol=1e-5)
 
 
+def test_agent_module_surface():
+    from dmmfods_amd.agents import Dense_U_Net_lidar_Agent as mod
+    for name in ("run", "train", "train_one_epoch", "validate", "save_checkpoint", "load_checkpoint", "finalize"):
+        assert callable(getattr(mod.Dense_U_Net_lidar_Agent, name))
+    class Opt:
+        param_groups = [dict(lr=1e-3)]
+    sch = mod._StepLR(Opt, 2, 0.1)
+    lrs = []
+    for _ in range(5):
+        sch.step()
+        lrs.append(Opt.param_groups[0]["lr"])
+    torch.testing.assert_close(torch.tensor(lrs), torch.tensor([1e-3, 1e-4, 1e-4, 1e-5, 1e-5]))
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):   # no CPU fallback: the agent refuses to run without a GPU
+            mod.Dense_U_Net_lidar_Agent(get_config("/tmp/x"), data_loader=object())
+
+
 @pytest.mark.gpu
 def test_agent_trains_validates_and_resumes(tmp_path):
     from dmmfods_amd.agents.Dense_U_Net_lidar_Agent import Dense_U_Net_lidar_Agent

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box: bench + rocprofv3 kernel-trace stats + PMC passes; leaves only small summaries under gpurun_out/$1.
+set -o pipefail
+tag=${1:-r01}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile"
+timeout -k 10 300 python3 bench.py --table --ops 2000 > $out/bench.json 2> $out/bench_classes_and_ops.txt || exit 1
+cat $out/bench.json
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- $B > $out/prof.log 2>&1 || exit 2
+cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o run -- $B > $out/pmcF.log 2>&1 || exit 3
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o run -- $B > $out/pmcW.log 2>&1 || exit 4
+python3 tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW $out/pmc_hbm_traffic.json > $out/pmc_hbm_traffic.txt || exit 5
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d /tmp/pmcS -o run -- $B > $out/pmcS.log 2>&1 || exit 6
+python3 tools/pmc_sq.py /tmp/pmcS $out/pmc_sq_summary.csv || exit 7
+ls -la $out
