@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmmfods_hip.so")
+LIB_PATH = os.environ.get("DMM_LIB_PATH") or os.path.join(_HERE, "libdmmfods_hip.so")  # DMM_LIB_PATH: experiment builds
 
 DMM_F32, DMM_F16 = 0, 1
 T_CONV, T_CONVT, T_BN_WEIGHT, T_BN_BIAS, T_BN_MEAN, T_BN_VAR, T_BN_TRACKED = range(7)

@@ -104,6 +104,15 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
 
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Neighbouring tiles share data
+// (conv halos, the operand that several K groups / N tiles re-read), so give every XCD one CONTIGUOUS range of the logical
+// tile order: logical = start(xcd) + blockIdx / 8.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int x = bid & 7, i = bid >> 3;
+  const int lo = nblocks >> 3, rem = nblocks & 7;
+  return x * lo + (x < rem ? x : rem) + i;
+}
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 #endif

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ntiles = a.Npad / BN;
-  const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mtile = lbid / ntiles, ntile = lbid - mtile * ntiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
 
   const int u = tid >> 7;          // chunk of the stage this thread gathers (wave-uniform)

@@ -11,11 +11,17 @@
 // operands are read from row-major LDS tiles with the hardware transposing read ds_read_b64_tr_b16 (16-bit
 // types) or plain ds_read_b32 (fp32).  A workgroup owns an n-tile (<=128) x 128 k-elements of dP and a range
 // of rows; partial sums are added to dP with fp32 atomics (128-byte contiguous segments per wave instruction).
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 #include "gather.h"
 
 namespace dmm {
 
+#ifndef WGRAD_DBG
+#define WGRAD_DBG 0  // timing experiments only: 1 skip atomics, 2 skip MFMA, 4 skip tile loads
+#endif
 constexpr int KW = 128;  // k elements per workgroup
 
 template <typename T> struct WgCfg;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = a.Npad / WBN;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % ntiles; bid /= ntiles;
   const int kg = bid % a.kgroups;
   const int split = bid / a.kgroups;
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     const bool more = mt + BMW < mend;
     if constexpr (!LIN) { if (more) fill_rowtab(which ^ 1, mt + BMW); }
     __syncthreads();
-    if (more) load_tiles(which ^ 1);
-    if (MFMA) {
+    if (more && !(WGRAD_DBG & 4)) load_tiles(which ^ 1);
+    if (MFMA && !(WGRAD_DBG & 2)) {
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int ms = 0; ms < BMW / 16; ++ms) {
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     const int ke = 32 * kt + r;
     const int chunk = kg * KCH + ke / BK;
     const int kk = ke % BK;
-    if (chunk >= total) continue;
+    if (chunk >= total || ((WGRAD_DBG & 1) && acc[t][0] != 123.f)) continue;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = n0 + 32 * wn + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -310,10 +316,13 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.rows_per_split <= 0) {
     const int wbn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
     const int base = a.kgroups * (a.Npad / wbn);
-    // aim for ~1024 workgroups, at least 4 row steps each, at most M/steps
-    int want = (1024 + base - 1) / base;
-    int steps = (a.M + bmw - 1) / bmw;
+    // ~1024 workgroups for short row ranges (every workgroup ends with WBN x 128 atomics); long ranges are cut finer, down
+    // to 32 row steps per workgroup, which evens out the tail of the launch
+    static const int target = getenv("DMM_WGRAD_WGS") ? atoi(getenv("DMM_WGRAD_WGS")) : 1024;
+    const int steps = (a.M + bmw - 1) / bmw;
+    const int want = (target + base - 1) / base, want_hi = (8 * target + base - 1) / base;
     int per = (steps + want - 1) / want;
+    if (per > 32) per = std::max(32, (steps + want_hi - 1) / want_hi);
     if (per < 4) per = 4;
     a.rows_per_split = per * bmw;
   }
