@@ -33,6 +33,13 @@ template <> struct Mma<float> {
 };
 
 constexpr int KS = 2;  // K-chunks per pipeline stage: twice the bytes in flight and twice the MFMAs per barrier
+#ifndef IGEMM_ADIST
+#define IGEMM_ADIST 2
+#endif
+#ifndef IGEMM_DBG
+#define IGEMM_DBG 0  // timing experiments only: 1 no A loads, 2 no prologue math, 4 no epilogue, 8 no weight DMA, 16 no MFMA
+#endif
+constexpr int ADIST = IGEMM_ADIST;  // register prefetch distance of the gathered operand, in stages (1 or 2)
 
 template <typename T, int BN>
 struct IgemmSmem {
@@ -222,23 +229,27 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     boff[q] = (n0 + nn) * BK + sl * SLOT;
   }
 
-  // issue-early / write-late: load_stage only issues the global loads of the next K-step; the prologue (BN+ReLU or the
-  // deferred-gradient correction) runs in store_stage one iteration later, after that step's MFMAs.
-  RawSlot<T> araw[4];
-  int sv_s = 0, sv_c = 0, sv_narr = 0;
-  int gnext = 0;  // first chunk of the next stage to issue
-  auto load_stage = [&](int buf) {
-    const int g = gnext + u;
-    gnext += KS;
-    const bool live = g < total;
-    {  // weights: LDS-DMA (a dead chunk re-reads chunk 0: its A slots are zero)
-      const T* bsrc = wp + (size_t)(live ? g : 0) * a.Npad * BK;
-      unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + u * BN * ROWB + (wave & 1) * NB * 1024;
+  // issue-early / write-late: issue_a only issues the global loads of a later K-step; the prologue (BN+ReLU or the
+  // deferred-gradient correction) runs in store_a ADIST iterations later, behind the MFMAs of the steps in between.  With
+  // ADIST = 2 two register sets alternate, so a step's loads have a whole iteration (not just one MFMA block) to land.
+  struct ARing {
+    RawSlot<T> raw[4];
+    int s, c, narr;
+  };
+  ARing R0, R1;
+  auto issue_b = [&](int buf, int stage) {  // weights: LDS-DMA (a dead chunk re-reads chunk 0: its A slots are zero)
+    const int g = stage * KS + u;
+    const T* bsrc = wp + (size_t)(g < total ? g : 0) * a.Npad * BK;
+    unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + u * BN * ROWB + (wave & 1) * NB * 1024;
 #pragma unroll
-      for (int q = 0; q < NB; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff[q]),
-                                         (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
-    }
+    for (int q = 0; q < NB; ++q)
+      if (!(IGEMM_DBG & 8)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff[q]),
+                                       (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
+  };
+  auto issue_a = [&](ARing& R, int stage) {
+    RawSlot<T>(&araw)[4] = R.raw;
+    const int g = stage * KS + u;
+    const bool live = g < total;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -248,12 +259,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     if constexpr (LIN) {
       const int c = g * BK + j * SLOT;
       const bool cv = live && c < su0.C;
-      sv_s = 0; sv_c = c; sv_narr = cv ? su0.narr : 0;
+      R.s = 0; R.c = c; R.narr = cv ? su0.narr : 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (cv && rv[i]) {
-          araw[i].v = *(const V*)((const T*)su0.src + roff[i] + c);
-          if (PRO == 2 || (PRO < 0 && su0.narr == 4)) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + c);
+          if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su0.src + roff[i] + c);
+          if (!(IGEMM_DBG & 1) && (PRO == 2 || (PRO < 0 && su0.narr == 4))) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + c);
           araw[i].state = 1;
         }
       }
@@ -264,10 +275,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     const SegU& su = s1 ? su1 : su0;
     const bool inside = (ent & 2) != 0;
     const int dy = (ent << 22) >> 24, dx = (ent << 14) >> 24, c = (int)((unsigned)ent >> 18);
-    sv_s = s1 ? 1 : 0; sv_c = c; sv_narr = inside ? su.narr : 0;
+    R.s = s1 ? 1 : 0; R.c = c; R.narr = inside ? su.narr : 0;
     if (su.mode == G_POOL2) {  // four loads + averaging: rare (transitions), done synchronously
-      const Seg& sg = a.seg[sv_s];
-      const SlotK<SLOT> kpool = lds_slot_consts<SLOT>(s1 ? lk1 : lk0, su.C, sv_narr, c);
+      const Seg& sg = a.seg[R.s];
+      const SlotK<SLOT> kpool = lds_slot_consts<SLOT>(s1 ? lk1 : lk0, su.C, R.narr, c);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (inside && rv[i]) {
@@ -285,34 +296,29 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       const int sy = ry[i] * su.istride + dy, sx = rx[i] * su.istride + dx;
       if (inside && rv[i] && (unsigned)sy < hl && (unsigned)sx < wl) {
         const size_t pix = (size_t)((rb[i] * su.Hs + (sy >> up)) * su.Ws + (sx >> up));
-        araw[i].v = *(const V*)((const T*)su.src + pix * su.ld + c);
-        if (two) araw[i].v2 = *(const V*)((const T*)su.src2 + pix * su.ld2 + c);
+        if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su.src + pix * su.ld + c);
+        if (!(IGEMM_DBG & 1) && two) araw[i].v2 = *(const V*)((const T*)su.src2 + pix * su.ld2 + c);
         araw[i].state = 1;
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_a = [&](const ARing& R, int buf) {
     unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
-    const float* lk = sv_s ? lk1 : lk0;
-    const int cst = sv_s ? su1.C : su0.C;
+    const float* lk = R.s ? lk1 : lk0;
+    const int cst = R.s ? su1.C : su0.C;
     SlotK<SLOT> kk;
-    if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(lk, cst, sv_c);
-    else kk = lds_slot_consts<SLOT>(lk, cst, sv_narr, sv_c);
+    if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(lk, cst, R.c);
+    else kk = lds_slot_consts<SLOT>(lk, cst, R.narr, R.c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = u * BM + rg + 32 * i;
-      *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = finish_slot<T, PRO>(sv_narr, araw[i], kk);
+      *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = (IGEMM_DBG & 2) ? R.raw[i].v : finish_slot<T, PRO>(R.narr, R.raw[i], kk);
     }
   };
 
   const int r = lane & 31, h = lane >> 5;
-  const int nstages = (total + KS - 1) / KS;
-  load_stage(0);
-  for (int it = 0; it < nstages; ++it) {
-    const int buf = it & 1;
-    store_stage(buf);
-    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
-    if (it + 1 < nstages) load_stage(buf ^ 1);
+  const int nstages = ((total + 2 * KS - 1) / (2 * KS)) * 2;  // even: the loop body holds two stages (a dead stage has zero A)
+  auto mma = [&](int buf) {
     const unsigned char* As = smem + buf * (SM::A_BYTES + SM::B_BYTES);
     const unsigned char* Bs = As + SM::A_BYTES;
     if (MFMA) {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const V bv = *(const V*)(Bs + (uu * BN + 32 * t + r) * ROWB + sw);
-            Mma<T>::run(acc[t], av, bv);
+            if (!(IGEMM_DBG & 16)) Mma<T>::run(acc[t], av, bv); else acc[t][0] += (float)av[0] * (float)bv[0];
           }
         }
     } else {
@@ -348,8 +354,54 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
           acc[t][i] += s;
         }
     }
+  };
+
+  ARing& RA = R0;
+  ARing& RB = ADIST == 2 ? R1 : R0;
+  issue_b(0, 0);
+  issue_a(RA, 0);
+  if (ADIST == 2) issue_a(RB, 1);
+  for (int it = 0; it < nstages; it += 2) {
+    store_a(RA, 0);
+    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+    issue_b(1, it + 1);
+    if (it + ADIST < nstages) issue_a(RA, it + ADIST);
+    mma(0);
+    store_a(RB, 1);
+    __syncthreads();
+    if (it + 2 < nstages) issue_b(0, it + 2);
+    if (it + 1 + ADIST < nstages) issue_a(RB, it + 1 + ADIST);
+    mma(1);
+  }
+  // ---- epilogue geometry: thread = (slot column cv, row phase rr), rows rr + RPP i ----
+  constexpr int NCV = BN / SLOT;       // slot columns in the tile
+  constexpr int RPP = NTHREADS / NCV;  // rows per pass
+  constexpr int NIT = BM / RPP;        // rows per thread
+  const int cv = tid % NCV, rr = tid / NCV;
+  const int n = n0 + cv * SLOT;
+  const bool colvalid = n < a.N;
+  // EPI_BNBWD reads x (and, when accumulating, the gradient) at every output position: issue those loads now, so that
+  // they fly while the accumulators are staged through LDS instead of serialising eight memory latencies per thread
+  V xpre[NIT], gpre[NIT];
+  int ppre[NIT];
+  const bool prefetched = EPI == EPI_BNBWD && !a.pool2;
+  if (EPI == EPI_BNBWD && prefetched) {
+    const T* bx = (const T*)a.bx;
+    const T* g = (const T*)a.out;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pix = rowpix[rr + RPP * i];
+      ppre[i] = colvalid ? pix : -1;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) { xpre[i][e] = (T)0; gpre[i][e] = (T)0; }
+      if (ppre[i] >= 0) {
+        xpre[i] = *(const V*)(bx + (size_t)pix * a.ldbx + n);
+        if (a.accumulate) gpre[i] = *(const V*)(g + (size_t)pix * a.ldo + n);
+      }
+    }
   }
   __syncthreads();  // all waves done with the operand image; reuse it for epilogue staging
+  if ((IGEMM_DBG & 4) && acc[0][0] != 123.f) return;
 
   // ---- stage the accumulators through LDS: Cs[row][col] ----
   if (EPI == EPI_STORE) {
@@ -387,11 +439,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     return;
   }
 
-  constexpr int NCV = BN / SLOT;       // slot columns in the tile
-  constexpr int RPP = NTHREADS / NCV;  // rows per pass
-  const int cv = tid % NCV, rr = tid / NCV;
-  const int n = n0 + cv * SLOT;
-  const bool colvalid = n < a.N;
   // per-thread partials cover <= 128/RPP rows: float is exact enough here; everything above this level is fp64
   float s1[SLOT], s2[SLOT];
 #pragma unroll
@@ -420,9 +467,32 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
       load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
     }
+    if (prefetched) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if (ppre[i] < 0) continue;
+        const int row = rr + RPP * i;
+        float av[SLOT], xf[SLOT], gf[SLOT];
+#pragma unroll
+        for (int e = 0; e < SLOT; e += 4) {
+          const f32x4 t4 = *(const f32x4*)(Cs + row * SM::STAGE_PITCH_F + cv * SLOT + e);
+          av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
+        }
+        vec_to_f32<T>(xpre[i], xf);
+        vec_to_f32<T>(gpre[i], gf);  // zeros unless accumulating
+#pragma unroll
+        for (int e = 0; e < SLOT; ++e) {
+          const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+          s1[e] += dz;
+          s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+          gf[e] += sc[e] * dz;
+        }
+        *(V*)(g + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
+      }
+    }
     const int nsub = a.pool2 ? 4 : 1;
     const float wgt = a.pool2 ? 0.25f : 1.f;
-    for (int row = rr; row < BM; row += RPP) {
+    for (int row = rr; row < BM && !prefetched; row += RPP) {
       const int pix = rowpix[row];
       if (pix < 0 || !colvalid) continue;
       float av[SLOT];
