@@ -83,49 +83,6 @@ __device__ __forceinline__ SegU seg_uniform(const Seg& sg) {
   return r;
 }
 
-// BN+ReLU on one 16-byte slot of f16: v_fma_mixlo/mixhi_f16 take the f16 half as an fp32 operand and round the fp32 fma
-// once to f16 (identical to (f16)fmaf((float)x, s, t)); ReLU commutes with that rounding and runs packed.
-__device__ __forceinline__ f16x8 bn_relu_slot(const f16x8& x, const SlotK<8>& k) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 xi = __builtin_bit_cast(u32x4, x);
-  u32x4 o;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    unsigned d;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xi[p]), "v"(k.k0[2 * p]), "v"(k.k1[2 * p]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "+v"(d) : "v"(xi[p]), "v"(k.k0[2 * p + 1]), "v"(k.k1[2 * p + 1]));
-    o[p] = d;
-  }
-  const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  return __builtin_elementwise_max(__builtin_bit_cast(f16x8, o), z);
-}
-__device__ __forceinline__ f32x4 bn_relu_slot(const f32x4& x, const SlotK<4>& k) {
-  f32x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(x[i], k.k0[i], k.k1[i]), 0.f);
-  return o;
-}
-
-// narr: 0 = no prologue, 2 = BN+ReLU, 4 = effective gradient (run-time value used by PRO < 0 only)
-template <typename T, int PRO>
-__device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {
-  constexpr int S = TT<T>::SLOT;
-  typename TT<T>::vec out = r.v;
-  const bool bn = PRO == 1 || (PRO < 0 && narr == 2);
-  const bool eg = PRO == 2 || (PRO < 0 && narr == 4);
-  if (PRO == 1 || (PRO < 0 && bn)) out = bn_relu_slot(r.v, k);
-  if (PRO == 2 || (PRO < 0 && eg)) {
-    float f[S], f2[S];
-    vec_to_f32<T>(r.v, f);
-    vec_to_f32<T>(r.v2, f2);
-#pragma unroll
-    for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
-    out = f32_to_vec<T>(f);
-  }
-  return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
-}
-
 template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int SLOT = TT<T>::SLOT;

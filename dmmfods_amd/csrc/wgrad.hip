@@ -19,6 +19,9 @@
 
 namespace dmm {
 
+#ifndef WGRAD_DIST_HEAVY
+#define WGRAD_DIST_HEAVY 1
+#endif
 #ifndef WGRAD_DBG
 #define WGRAD_DBG 0  // timing experiments only: 1 skip atomics, 2 skip MFMA, 4 skip tile loads
 #endif
@@ -31,18 +34,23 @@ template <> struct WgCfg<float> { static constexpr int BMW = 32; };
 template <typename T, int WBN>
 struct WgradSmem {
   static constexpr int BMW = WgCfg<T>::BMW;
-  // pitches chosen so that (pitch/4) mod 64 is 16 or 48: 4 consecutive rows of a transposed read tile the banks
+  // 256-byte rows of 16-bit elements (128 columns) are stored unpadded with the 64-byte granule index XOR-ed with (row & 3); other row
+  // lengths are padded so that (pitch/4) mod 64 is 16 or 48.  Either way 4 consecutive rows of a transposed read tile
+  // the banks.
   static constexpr int pitch_for(int row_bytes) {
+    if (row_bytes == 256 && sizeof(T) == 2) return 256;
     int p = row_bytes;
     while (((p / 4) % 64) != 16 && ((p / 4) % 64) != 48) p += 16;
     return p;
   }
   static constexpr int PD = pitch_for(WBN * (int)sizeof(T));
   static constexpr int PA = pitch_for(KW * (int)sizeof(T));
+  static constexpr bool SWZ_D = PD == 256 && sizeof(T) == 2, SWZ_A = PA == 256 && sizeof(T) == 2;
   static constexpr int D_BYTES = BMW * PD;
   static constexpr int A_BYTES = BMW * PA;
-  static constexpr int TAB = 2 * BMW * 16;  // two row tables of int4 {b, y, x, valid}
-  static constexpr int bytes = D_BYTES + A_BYTES + TAB;
+  static constexpr int BUF = D_BYTES + A_BYTES;  // one of the two operand buffers
+  static constexpr int TAB = 2 * BMW * 16;       // two row tables of int4 {b, y, x, valid}
+  static constexpr int bytes = 2 * BUF + TAB;
 };
 
 __device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
@@ -54,7 +62,9 @@ __device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
 // PP / PQ = prologue kind of the pixel-aligned operand P and of the tapped operand Q (-1 run time, 0 none, 1 BN+ReLU,
 // 2 effective gradient); LIN = both operands are plain one-tap unit-stride tensors on the row grid (1x1 layers): the
 // source pixel is the row index, no row table and no coordinate arithmetic.
-template <typename T, int WBN, bool MFMA, int PP, int PQ, bool LIN>
+// Pipeline: two LDS operand buffers (one barrier per row tile) and DIST register sets: the loads of tile t + DIST are
+// issued right after the barrier of tile t and are consumed (prologue + ds_write) DIST iterations later.
+template <typename T, int WBN, bool MFMA, int PP, int PQ, bool LIN, int DIST>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
@@ -68,9 +78,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int NCD = WBN / SLOT, RGD = NTHREADS / NCD, LD = (BMW + RGD - 1) / RGD;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ds = smem;
-  unsigned char* As = smem + SM::D_BYTES;
-  int4* rowtab = (int4*)(smem + SM::D_BYTES + SM::A_BYTES);
+  int4* rowtab = (int4*)(smem + 2 * SM::BUF);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = a.Npad / WBN;
@@ -105,69 +113,132 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   const SlotK<SLOT> preQ = load_slot_consts<SLOT>(a.seg[ks], ktap < a.seg[ks].ntaps ? kc : -1);
   const SlotK<SLOT> preP = load_slot_consts<SLOT>(a.dy, nD < a.N ? nD : -1);
 
-  auto fill_rowtab = [&](int which, int mt) {
+  // row tables (non-LIN): lane tid < BMW walks its row (b, y, x) from tile to tile without divisions
+  int wb = 0, wy = 0, wx = 0, wm = mbeg + tid;
+  if (!LIN && tid < BMW) row_to_byx(min(wm, a.M - 1), a.Ho, a.Wo, wb, wy, wx);
+  auto fill_rowtab = [&](int slot) {  // writes the table of the walker's current tile, then advances one tile
     if (tid < BMW) {
-      const int m = mt + tid;
-      int4 e;
-      if (m < mend) {
-        row_to_byx(m, a.Ho, a.Wo, e.x, e.y, e.z);
-        e.w = 1;
-      } else {
-        e.x = e.y = e.z = 0;
-        e.w = -1;
+      rowtab[slot * BMW + tid] = wm < mend ? make_int4(wb, wy, wx, 1) : make_int4(0, 0, 0, -1);
+      wm += BMW;
+      wx += BMW;
+      while (wx >= a.Wo) {
+        wx -= a.Wo;
+        if (++wy >= a.Ho) { wy = 0; ++wb; }
       }
-      rowtab[which * BMW + tid] = e;
     }
   };
 
-  // issue-early / write-late (see igemm.hip): raw loads now, prologue when the tile is written to LDS one step later
-  RawSlot<T> araw[LA], draw[LD];
-  int mt_next = mbeg;  // first row of the tile load_tiles() will fetch (LIN)
-  auto lin_issue = [&](const Seg& sg, RawSlot<T>& rs, int m, int c, bool cvalid, bool want2) {
+  // issue-early / write-late (see igemm.hip): raw loads now, prologue when the tile is written to LDS DIST steps later
+  struct Ring {
+    RawSlot<T> q[LA], p[LD];
+  };
+  Ring R0, R1;
+  // The tapped operand's segment depends on the thread's K position, so a.seg[ks] is a per-LANE address: everything the
+  // tile loop needs from it is copied into registers here (left in the loop, every field access is a vector load from
+  // the kernel-argument segment in front of the data load that depends on it).
+  const Seg& sgq = a.seg[ks];
+  const bool qinside = ktap < sgq.ntaps && kc < sgq.C;
+  const int qnarr = sgq.scale ? 2 : (sgq.q ? 4 : 0);
+  const bool qtwo = PQ == 2 || (PQ < 0 && qnarr == 4);
+  const T* const qsrc = (const T*)sgq.src + kc;
+  const T* const qsrc2 = (const T*)sgq.src2 + kc;
+  const int qld = sgq.ld, qld2 = sgq.ld2, qHs = sgq.Hs, qWs = sgq.Ws, qistr = sgq.istride;
+  const bool qpool = sgq.mode == G_POOL2;
+  const int qup = sgq.mode == G_UP2 ? 1 : 0;
+  int qdy = 0, qdx = 0;
+  if (qinside) {
+    const int t = sgq.taps[ktap];
+    qdy = (int)(signed char)(t & 0xff);
+    qdx = (int)(signed char)((t >> 8) & 0xff);
+  }
+  // the pixel-aligned operand: one segment for all threads (wave-uniform fields)
+  const int pnarr = a.dy.scale ? 2 : (a.dy.q ? 4 : 0);
+  const bool ptwo = PP == 2 || (PP < 0 && pnarr == 4);
+  const bool pvalid = nD < a.N;
+  const T* const psrc = (const T*)a.dy.src + (pvalid ? nD : 0);
+  const T* const psrc2 = (const T*)a.dy.src2 + (pvalid ? nD : 0);
+  int pdy, pdx;
+  {
+    const int t = a.dy.taps[0];
+    pdy = (int)(signed char)(t & 0xff);
+    pdx = (int)(signed char)((t >> 8) & 0xff);
+  }
+
+  auto zero_slot = [&](RawSlot<T>& rs) {
 #pragma unroll
     for (int e = 0; e < SLOT; ++e) { rs.v[e] = (T)0; rs.v2[e] = (T)0; }
     rs.state = 0;
-    if (cvalid && m < mend) {
-      rs.v = *(const V*)((const T*)sg.src + (size_t)m * sg.ld + c);
-      if (want2) rs.v2 = *(const V*)((const T*)sg.src2 + (size_t)m * sg.ld2 + c);
-      rs.state = 1;
-    }
   };
-  auto load_tiles = [&](int which) {
-    const Seg& sg = a.seg[ks];
+  auto issue = [&](Ring& R, int mt, int slot) {
     if constexpr (LIN) {
-      const bool qv = ktap < sg.ntaps && kc < sg.C;
 #pragma unroll
-      for (int i = 0; i < LA; ++i) lin_issue(sg, araw[i], mt_next + rga + i * RGA, kc, qv, PQ == 2 || (PQ < 0 && sg.q != nullptr));
+      for (int i = 0; i < LA; ++i) {
+        const int m = mt + rga + i * RGA;
+        zero_slot(R.q[i]);
+        if (qinside && m < mend) {
+          R.q[i].v = *(const V*)(qsrc + (size_t)m * qld);
+          if (qtwo) R.q[i].v2 = *(const V*)(qsrc2 + (size_t)m * qld2);
+          R.q[i].state = 1;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < LD; ++i) {
-        const int row = rgd + i * RGD;
-        lin_issue(a.dy, draw[i], mt_next + row, nD < a.N ? nD : 0, nD < a.N && row < BMW, PP == 2 || (PP < 0 && a.dy.q != nullptr));
+        const int row = rgd + i * RGD, m = mt + row;
+        zero_slot(R.p[i]);
+        if (pvalid && row < BMW && m < mend) {
+          R.p[i].v = *(const V*)(psrc + (size_t)m * a.dy.ld);
+          if (ptwo) R.p[i].v2 = *(const V*)(psrc2 + (size_t)m * a.dy.ld2);
+          R.p[i].state = 1;
+        }
       }
-      mt_next += BMW;
       return;
     }
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int4 e = rowtab[which * BMW + rga + i * RGA];
-      araw[i] = gather_issue<T>(sg, e.x, e.y, e.z, e.w > 0, ktap, kc, preQ);
+      const int4 e = rowtab[slot * BMW + rga + i * RGA];
+      if (qpool) {  // pooled transition input: four loads + BN + averaging, done synchronously (rare)
+        R.q[i] = gather_issue<T>(sgq, e.x, e.y, e.z, e.w > 0, ktap, kc, preQ);
+        continue;
+      }
+      zero_slot(R.q[i]);
+      const int sy = e.y * qistr + qdy, sx = e.z * qistr + qdx;
+      if (qinside && e.w > 0 && (unsigned)sy < ((unsigned)qHs << qup) && (unsigned)sx < ((unsigned)qWs << qup)) {
+        const size_t pix = (size_t)((e.x * qHs + (sy >> qup)) * qWs + (sx >> qup));
+        R.q[i].v = *(const V*)(qsrc + pix * qld);
+        if (qtwo) R.q[i].v2 = *(const V*)(qsrc2 + pix * qld2);
+        R.q[i].state = 1;
+      }
     }
+    const int pup = a.dy.mode == G_UP2 ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int row = rgd + i * RGD;
       int4 e = {0, 0, 0, 0};
-      if (row < BMW) e = rowtab[which * BMW + row];
-      draw[i] = gather_issue<T>(a.dy, e.x, e.y, e.z, e.w > 0 && nD < a.N, 0, nD < a.N ? nD : 0, preP);
+      if (row < BMW) e = rowtab[slot * BMW + row];
+      zero_slot(R.p[i]);
+      const int sy = e.y * a.dy.istride + pdy, sx = e.z * a.dy.istride + pdx;
+      if (pvalid && e.w > 0 && (unsigned)sy < ((unsigned)a.dy.Hs << pup) && (unsigned)sx < ((unsigned)a.dy.Ws << pup)) {
+        const size_t pix = (size_t)((e.x * a.dy.Hs + (sy >> pup)) * a.dy.Ws + (sx >> pup));
+        R.p[i].v = *(const V*)(psrc + pix * a.dy.ld);
+        if (ptwo) R.p[i].v2 = *(const V*)(psrc2 + pix * a.dy.ld2);
+        R.p[i].state = 1;
+      }
     }
   };
-  auto store_tiles = [&]() {
-    const Seg& sg = a.seg[ks];
+  auto store = [&](const Ring& R, int buf) {
+    unsigned char* Ds = smem + buf * SM::BUF;
+    unsigned char* As = Ds + SM::D_BYTES;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *(V*)(As + (rga + i * RGA) * SM::PA + ca * 16) = gather_finish<T, PQ>(sg, araw[i], preQ);
+    for (int i = 0; i < LA; ++i) {
+      const int row = rga + i * RGA;
+      const int col = SM::SWZ_A ? ((ca * 16) ^ ((row & 3) << 6)) : ca * 16;
+      *(V*)(As + row * SM::PA + col) = (WGRAD_DBG & 8) ? R.q[i].v : finish_slot<T, PQ>(qnarr, R.q[i], preQ);
+    }
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int row = rgd + i * RGD;
-      if (row < BMW) *(V*)(Ds + row * SM::PD + cd * 16) = gather_finish<T, PP>(a.dy, draw[i], preP);
+      const int col = SM::SWZ_D ? ((cd * 16) ^ ((row & 3) << 6)) : cd * 16;
+      if (row < BMW) *(V*)(Ds + row * SM::PD + col) = (WGRAD_DBG & 8) ? R.p[i].v : finish_slot<T, PP>(pnarr, R.p[i], preP);
     }
   };
 
@@ -182,22 +253,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   // transposed-read lane geometry (16-bit types): group g = lane>>4 covers columns 16*(g&1).., rows 8*(g>>1)..
   const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
 
-  if constexpr (!LIN) fill_rowtab(0, mbeg);
-  __syncthreads();
-  load_tiles(0);
-  int which = 0;
-  for (int mt = mbeg; mt < mend; mt += BMW) {
-    store_tiles();
-    const bool more = mt + BMW < mend;
-    if constexpr (!LIN) { if (more) fill_rowtab(which ^ 1, mt + BMW); }
-    __syncthreads();
-    if (more && !(WGRAD_DBG & 4)) load_tiles(which ^ 1);
-    if (MFMA && !(WGRAD_DBG & 2)) {
+  auto mma = [&](int buf) {
+    const unsigned char* Ds = smem + buf * SM::BUF;
+    const unsigned char* As = Ds + SM::D_BYTES;
+    if (MFMA && !(WGRAD_DBG & (2 | 32))) {
       if constexpr (sizeof(T) == 2) {
+        // rows read by this lane are 16 ms + 8 (tg >> 1) + tq (+4): row & 3 == tq, so the swizzle term is a lane constant
+        const int dcol = (32 * wn + 16 * (tg & 1) + 4 * tp) * 2;
+        const int dsw = SM::SWZ_D ? (dcol ^ (tq << 6)) : dcol;
 #pragma unroll
         for (int ms = 0; ms < BMW / 16; ++ms) {
           const int rowb = 16 * ms + 8 * (tg >> 1) + tq;
-          const unsigned char* dp = Ds + rowb * SM::PD + (32 * wn + 16 * (tg & 1) + 4 * tp) * 2;
+          const unsigned char* dp = Ds + rowb * SM::PD + dsw;
           f16x4 lo = lds_tr16(dp), hi = lds_tr16(dp + 4 * SM::PD);
           f16x8 af;
           af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
@@ -205,7 +272,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
           for (int t = 0; t < TPW; ++t) {
             const int kt = wk * TPW + t;
-            const unsigned char* ap = As + rowb * SM::PA + (32 * kt + 16 * (tg & 1) + 4 * tp) * 2;
+            const int acol = (32 * kt + 16 * (tg & 1) + 4 * tp) * 2;
+            const unsigned char* ap = As + rowb * SM::PA + (SM::SWZ_A ? (acol ^ (tq << 6)) : acol);
             f16x4 blo = lds_tr16(ap), bhi = lds_tr16(ap + 4 * SM::PA);
             f16x8 bf;
             bf[0] = blo[0]; bf[1] = blo[1]; bf[2] = blo[2]; bf[3] = blo[3];
@@ -226,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
           }
         }
       }
-    } else {
+    } else if (!MFMA) {
       // scalar check path, same accumulator layout: acc[t][i] <-> (n = 32*wn + rowmap(i), k = 32*kt + r)
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
@@ -235,15 +303,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
         for (int i = 0; i < 16; ++i) {
           const int nrow = 32 * wn + (i & 3) + 8 * (i >> 2) + 4 * h;
           float s = 0.f;
-          for (int m = 0; m < BMW; ++m)
-            s = fmaf(to_f32(*(const T*)(Ds + m * SM::PD + nrow * sizeof(T))),
-                     to_f32(*(const T*)(As + m * SM::PA + (32 * kt + r) * sizeof(T))), s);
+          for (int m = 0; m < BMW; ++m) {
+            const int dc = nrow * (int)sizeof(T), ac = (32 * kt + r) * (int)sizeof(T);
+            s = fmaf(to_f32(*(const T*)(Ds + m * SM::PD + (SM::SWZ_D ? (dc ^ ((m & 3) << 6)) : dc))),
+                     to_f32(*(const T*)(As + m * SM::PA + (SM::SWZ_A ? (ac ^ ((m & 3) << 6)) : ac))), s);
+          }
           acc[t][i] += s;
         }
       }
     }
+  };
+
+  // tiles are processed in pairs (one per register set / LDS buffer); a tile past mend gathers zeros
+  const int npairs = ((mend - mbeg) + 2 * BMW - 1) / (2 * BMW);
+  Ring& RA = R0;
+  Ring& RB = DIST == 2 ? R1 : R0;
+  if constexpr (!LIN) {
+    fill_rowtab(0);
+    if (DIST == 2) fill_rowtab(1);
     __syncthreads();
-    which ^= 1;
+  }
+  issue(RA, mbeg, 0);
+  if (DIST == 2) issue(RB, mbeg + BMW, 1);
+  for (int pr = 0; pr < npairs; ++pr) {
+    const int mt = (WGRAD_DBG & 16) ? mbeg : mbeg + pr * 2 * BMW;
+    // the tile whose loads are issued in this half goes to table slot (tile index & 1); the walker is DIST tiles ahead
+    store(RA, 0);
+    if constexpr (!LIN) fill_rowtab(DIST == 2 ? 0 : 1);
+    __syncthreads();
+    if (!(WGRAD_DBG & 4)) issue(RA, mt + DIST * BMW, DIST == 2 ? 0 : 1);
+    mma(0);
+    if (WGRAD_DBG & 32) acc[0][0] += *(const float*)(smem + lane * 4);
+    store(RB, 1);
+    if constexpr (!LIN) fill_rowtab(DIST == 2 ? 1 : 0);
+    __syncthreads();
+    if (!(WGRAD_DBG & 4)) issue(RB, mt + (1 + DIST) * BMW, DIST == 2 ? 1 : 0);
+    mma(1);
   }
 
   // ---- add the partial tile to the packed gradient ----
@@ -262,6 +357,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// register prefetch distance per variant: two sets unless the raw operands (two tensors each for the effective
+// gradient) would not fit the register budget of two workgroups per CU
+constexpr int WDIST(int wbn, int pp, int pq) { return ((pp == 2 || pq == 2 || pp < 0) && wbn == 128) ? WGRAD_DIST_HEAVY : 2; }
+
 static int seg_pro(const Seg& sg) { return sg.mode == G_POOL2 ? -1 : (sg.scale ? 1 : (sg.q ? 2 : 0)); }
 static bool seg_lin(const Seg& sg, const WgradArgs& a) {
   return sg.ntaps == 1 && sg.taps[0] == 0 && sg.mode == G_PLAIN && sg.istride == 1 && sg.Hs == a.Ho && sg.Ws == a.Wo;
@@ -279,15 +378,15 @@ static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
   const bool lin = a.nseg == 1 && seg_lin(a.seg[0], a) && seg_lin(a.dy, a);
   void (*kern)(const WgradArgs);
   int ai;
-  if (!mfma) { kern = wgrad_kernel<T, WBN, false, -1, -1, false>; ai = 0; }
-  else if (lin && pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, true>; ai = 1; }
-  else if (lin && pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, true>; ai = 7; }
-  else if (pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, false>; ai = 8; }
-  else if (pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, false>; ai = 2; }
-  else if (pp == 1 && pq == 2) { kern = wgrad_kernel<T, WBN, true, 1, 2, false>; ai = 3; }
-  else if (pp == 2 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 2, 0, false>; ai = 4; }
-  else if (pp == 1 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 1, 0, false>; ai = 5; }
-  else { kern = wgrad_kernel<T, WBN, true, -1, -1, false>; ai = 6; }
+  if (!mfma) { kern = wgrad_kernel<T, WBN, false, -1, -1, false, WDIST(WBN, -1, -1)>; ai = 0; }
+  else if (lin && pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, true, WDIST(WBN, 2, 1)>; ai = 1; }
+  else if (lin && pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, true, WDIST(WBN, 0, 1)>; ai = 7; }
+  else if (pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, false, WDIST(WBN, 0, 1)>; ai = 8; }
+  else if (pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, false, WDIST(WBN, 2, 1)>; ai = 2; }
+  else if (pp == 1 && pq == 2) { kern = wgrad_kernel<T, WBN, true, 1, 2, false, WDIST(WBN, 1, 2)>; ai = 3; }
+  else if (pp == 2 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 2, 0, false, WDIST(WBN, 2, 0)>; ai = 4; }
+  else if (pp == 1 && pq == 0) { kern = wgrad_kernel<T, WBN, true, 1, 0, false, WDIST(WBN, 1, 0)>; ai = 5; }
+  else { kern = wgrad_kernel<T, WBN, true, -1, -1, false, WDIST(WBN, -1, -1)>; ai = 6; }
   static bool attr_done[9] = {false, false, false, false, false, false, false, false, false};
   if (SM::bytes > 48 * 1024 && !attr_done[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
