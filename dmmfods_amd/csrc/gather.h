@@ -311,22 +311,40 @@ __device__ __forceinline__ f32x4 bn_relu_slot(const f32x4& x, const SlotK<4>& k)
   return o;
 }
 
+// Effective gradient g + q[c] + r[c]*x on one slot.  fp32 tensors use the hi/lo split constants (exact to ~1e-14, the
+// parity configuration); for f16 tensors the lo parts are far below the storage rounding, so the slot costs two mixed
+// instructions per element: t = fma(f32(x), r, q) and f16(f32(g) + t), rounded once.
+__device__ __forceinline__ f16x8 eff_grad_slot(const f16x8& g, const f16x8& x, const SlotK<8>& k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 gi = __builtin_bit_cast(u32x4, g), xi = __builtin_bit_cast(u32x4, x);
+  const float one = 1.f;
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float t0, t1;
+    unsigned d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(xi[p]), "v"(k.k1[2 * p]), "v"(k.k0[2 * p]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=v"(t1) : "v"(xi[p]), "v"(k.k1[2 * p + 1]), "v"(k.k0[2 * p + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(gi[p]), "v"(one), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(gi[p]), "v"(one), "v"(t1));
+    o[p] = d;
+  }
+  return __builtin_bit_cast(f16x8, o);
+}
+__device__ __forceinline__ f32x4 eff_grad_slot(const f32x4& g, const f32x4& x, const SlotK<4>& k) {
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (g[i] + fmaf(k.k1[i], x[i], k.k0[i])) + fmaf(k.k3[i], x[i], k.k2[i]);
+  return o;
+}
+
 // narr: 0 = no prologue, 2 = BN+ReLU, 4 = effective gradient (run-time value used by PRO < 0 only)
 template <typename T, int PRO>
 __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {
-  constexpr int S = TT<T>::SLOT;
   typename TT<T>::vec out = r.v;
-  const bool bn = PRO == 1 || (PRO < 0 && narr == 2);
-  const bool eg = PRO == 2 || (PRO < 0 && narr == 4);
-  if (PRO == 1 || (PRO < 0 && bn)) out = bn_relu_slot(r.v, k);
-  if (PRO == 2 || (PRO < 0 && eg)) {
-    float f[S], f2[S];
-    vec_to_f32<T>(r.v, f);
-    vec_to_f32<T>(r.v2, f2);
-#pragma unroll
-    for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
-    out = f32_to_vec<T>(f);
-  }
+  if (PRO == 1 || (PRO < 0 && narr == 2)) out = bn_relu_slot(r.v, k);
+  if (PRO == 2 || (PRO < 0 && narr == 4)) out = eff_grad_slot(r.v, r.v2, k);
   return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
 }
 

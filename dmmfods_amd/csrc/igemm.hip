@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     const float* lk = R.s ? lk1 : lk0;
     const int cst = R.s ? su1.C : su0.C;
     SlotK<SLOT> kk;
-    if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? 4 : 0)>(lk, cst, R.c);
+    if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? (sizeof(T) == 2 ? 2 : 4) : 0)>(lk, cst, R.c);
     else kk = lds_slot_consts<SLOT>(lk, cst, R.narr, R.c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
