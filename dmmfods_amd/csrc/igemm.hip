@@ -34,7 +34,7 @@ template <> struct Mma<float> {
 
 constexpr int KS = 2;  // K-chunks per pipeline stage: twice the bytes in flight and twice the MFMAs per barrier
 #ifndef IGEMM_ADIST
-#define IGEMM_ADIST 2
+#define IGEMM_ADIST 1
 #endif
 #ifndef IGEMM_DBG
 #define IGEMM_DBG 0  // timing experiments only: 1 no A loads, 2 no prologue math, 4 no epilogue, 8 no weight DMA, 16 no MFMA
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     const bool inside = (ent & 2) != 0;
     const int dy = (ent << 22) >> 24, dx = (ent << 14) >> 24, c = (int)((unsigned)ent >> 18);
     R.s = s1 ? 1 : 0; R.c = c; R.narr = inside ? su.narr : 0;
-    if (su.mode == G_POOL2) {  // four loads + averaging: rare (transitions), done synchronously
+    if (PRO < 0 && su.mode == G_POOL2) {  // four loads + averaging: rare (transitions, always the run-time variant), synchronous
       const Seg& sg = a.seg[R.s];
       const SlotK<SLOT> kpool = lds_slot_consts<SLOT>(s1 ? lk1 : lk0, su.C, R.narr, c);
 #pragma unroll
