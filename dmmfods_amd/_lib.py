@@ -53,6 +53,8 @@ def lib():
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     L.dmm_last_error.restype = C.c_char_p
     L.dmm_version.restype = C.c_int
+    L.dmm_set_option.restype = C.c_int
+    L.dmm_set_option.argtypes = [C.c_char_p, C.c_int]
     L.dmm_plan_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dmm_plan_destroy.argtypes = [vp]
     L.dmm_plan_destroy.restype = None
@@ -87,7 +89,7 @@ def lib():
 
 
 EXPORTS = [
-    "dmm_last_error", "dmm_version", "dmm_plan_create", "dmm_plan_destroy", "dmm_plan_num_tensors",
+    "dmm_last_error", "dmm_version", "dmm_set_option", "dmm_plan_create", "dmm_plan_destroy", "dmm_plan_num_tensors",
     "dmm_plan_tensor_info", "dmm_plan_num_params", "dmm_plan_num_buffer_elems", "dmm_plan_workspace_bytes",
     "dmm_plan_forward_flops", "dmm_plan_bind", "dmm_plan_forward", "dmm_plan_loss_backward", "dmm_plan_backward",
     "dmm_plan_loss_metrics", "dmm_plan_profile_begin", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",

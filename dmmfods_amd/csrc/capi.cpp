@@ -28,6 +28,12 @@ extern "C" {
 const char* dmm_last_error(void) { return g_err.c_str(); }
 int dmm_version(void) { return 100; }
 
+int dmm_set_option(const char* name, int value) {
+  if (!name) return fail(DMM_ERR_INVALID, "null argument");
+  if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
+  return fail(DMM_ERR_INVALID, std::string("unknown option ") + name);
+}
+
 int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   if (!desc || !out) return fail(DMM_ERR_INVALID, "null argument");
   if (desc->num_blocks < 2 || desc->num_blocks > 8) return fail(DMM_ERR_INVALID, "num_blocks must be in [2, 8]");

@@ -545,9 +545,14 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
 }
 
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // halo.hip
+hipError_t launch_thin_logits(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // thin.hip
 
 hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
+  if (mfma) {  // few output channels x many taps: gather once, reduce the taps in LDS
+    const hipError_t e = launch_thin_logits(a, dtype, epi, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;
   if (mfma && !no_halo) {  // multi-tap layers whose weights fit in LDS may take the halo-tile kernel
     const hipError_t e = launch_halo(a, dtype, epi, st);

@@ -1,0 +1,244 @@
+// Thin-output convolution for gfx950: few output channels (N <= 4), many taps - the 5x5 heat-map head
+// (dec_out_to_heat_maps.refine1, reference M:233-237: 64 -> num_classes).
+//
+// As an implicit GEMM this layer wastes the matrix core on padding (N = 3 of a 32-wide tile) and gathers every input
+// pixel 25 times.  Here every input pixel is gathered ONCE: a 1x1 GEMM produces, per input pixel, the products with all
+// (tap, class) weight columns (25*3 = 75 of 96 MFMA columns), and the convolution sum over taps becomes a shifted
+// reduction of those partial products in LDS:
+//     logits[y][x][cls] = sum_tap  P[y + dy_tap][x + dx_tap][tap*N + cls],   P[p][tap*N + cls] = sum_c relu(bn(x[p][c])) w[cls][c][tap]
+// A workgroup walks down a strip of 128 input columns (124 output columns for a 5x5), one input row per step:
+//   gather + BN + ReLU (registers -> LDS, issued one row ahead) -> 12 MFMA per wave with the weight fragments held in
+//   registers -> P[96][128] fp32 to LDS -> per output column, add the row's taps into a ring of 2R+2 output rows
+//   -> the output row completed by the previous step is written out (fp32 NCHW) and its ring slot cleared.
+// 16-bit storage only; fp32 tensors stay on the generic kernels (the parity configuration).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "gather.h"
+
+namespace dmm {
+
+constexpr int TH_PX = 128;        // input pixels per row step (4 waves x 32)
+constexpr int TH_COLS = 96;       // MFMA columns (tap*N + cls)
+constexpr int TH_PP = TH_PX + 4;  // floats per P column (pitch 132 words: b128 writes of 32 columns spread over the banks)
+constexpr int TH_RING = 6;        // output rows in flight: 2R+1 receive taps, one is being written out
+constexpr int TH_MAXTAPS = 32;
+
+struct ThinArgs {
+  const f16* src;
+  int ld, B, H, W;
+  const float* scale;
+  const float* shift;
+  const f16* wpack;  // forward pack [chunk = tap*2 + c/32][Npad][32]
+  int Npad, N, ntaps, R;
+  float* logits;  // fp32 NCHW (B, N, H, W)
+  int rows_per_wg, nys, nxs;
+  signed char dy[TH_MAXTAPS], dx[TH_MAXTAPS];
+};
+
+struct ThinSmem {
+  static constexpr int A_BYTES = 2 * TH_PX * ROWB;            // two 32-channel chunks
+  static constexpr int P_BYTES = TH_COLS * TH_PP * 4;
+  static constexpr int O_BYTES = TH_RING * 4 * TH_PX * 4;     // ring[slot][cls < 4][xl]
+  static constexpr int bytes = A_BYTES + P_BYTES + O_BYTES;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;
+  float* Ps = (float*)(smem + ThinSmem::A_BYTES);
+  float* Os = (float*)(smem + ThinSmem::A_BYTES + ThinSmem::P_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int xs = bid % a.nxs; bid /= a.nxs;
+  const int ys = bid % a.nys;
+  const int b = bid / a.nys;
+  const int R = a.R;
+  const int wout = TH_PX - 2 * R;  // output columns per strip
+  const int x0 = xs * wout, y0 = ys * a.rows_per_wg;
+  const int ncols = a.ntaps * a.N;
+
+  // ---- gather role: slot column j (8 channels), pixels pg + 32 i ----
+  const int j = tid & 7, pg = tid >> 3;
+  SlotK<8> kk;
+  kk.k0 = load_fv<8>(a.scale + 8 * j);
+  kk.k1 = load_fv<8>(a.shift + 8 * j);
+  kk.k2 = 0.f; kk.k3 = 0.f;
+  int gx[4];
+  bool gxok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gx[i] = x0 - R + pg + 32 * i;
+    gxok[i] = gx[i] >= 0 && gx[i] < a.W;
+  }
+  const int aoff = ((j >> 2) * TH_PX) * ROWB + (((j & 3) ^ ((pg >> 2) & 3)) << 4);  // + px * ROWB; (px >> 2) & 3 == (pg >> 2) & 3
+
+  // ---- MFMA role: weight fragments of this lane's column, kept in registers for the whole strip ----
+  const int r = lane & 31, h = lane >> 5;
+  f16x8 bfrag[2][2][3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int col = 32 * t + r;
+    const int tap = col / a.N, cls = col - tap * a.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bfrag[u][s][t][e] = (f16)0;
+        if (col < ncols) bfrag[u][s][t] = *(const f16x8*)(a.wpack + ((size_t)(tap * 2 + u) * a.Npad + cls) * 32 + (2 * s + h) * 8);
+      }
+  }
+
+  // ---- reduce role: output column xl, taps [tbeg, tend) ----
+  const int xl = tid & 127, half = tid >> 7;
+  const int tmid = (a.ntaps + 1) / 2;
+  const int tbeg = half ? tmid : 0, tend = half ? a.ntaps : tmid;
+
+  for (int i = tid; i < TH_RING * 4 * TH_PX; i += NTHREADS) Os[i] = 0.f;
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f16x8 raw[4];
+  bool rawok[4];
+  auto issue = [&](int iy) {
+    const bool rowok = iy >= 0 && iy < a.H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rawok[i] = rowok && gxok[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[i][e] = (f16)0;
+      if (rawok[i]) raw[i] = *(const f16x8*)(a.src + ((size_t)(b * a.H + iy) * a.W + gx[i]) * a.ld + 8 * j);
+    }
+  };
+
+  const int nsteps = a.rows_per_wg + 2 * R;
+  const int yend = min(a.H, y0 + a.rows_per_wg);
+  issue(y0 - R);
+  __syncthreads();  // ring cleared
+  for (int it = 0; it <= nsteps; ++it) {
+    const int iy = y0 - R + it;  // input row of this step (it == nsteps: drain, only writes the last output row)
+    if (it < nsteps) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f16x8 v = bn_relu_slot(raw[i], kk);
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (f16)0;
+        *(f16x8*)(As + aoff + (pg + 32 * i) * ROWB) = rawok[i] ? v : z;  // zero padding applies AFTER BN+ReLU
+      }
+    }
+    __syncthreads();  // A image complete; previous step's reduction has finished reading P
+    if (it < nsteps) {
+      if (it + 1 < nsteps) issue(iy + 1);
+      f32x16 acc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f16x8 av = *(const f16x8*)(As + (u * TH_PX + 32 * wave + r) * ROWB + (((2 * s + h) ^ ((r >> 2) & 3)) << 4));
+#pragma unroll
+          for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bfrag[u][s][t], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int col = 32 * t + r;
+        if (col < ncols) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v4 = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *(f32x4*)(Ps + col * TH_PP + 32 * wave + 8 * g + 4 * h) = v4;
+          }
+        }
+      }
+    }
+    __syncthreads();  // P complete
+    // write out the row completed by the previous step and clear its slot (no tap of this step lands there)
+    {
+      const int yd = iy - 1 - R;
+      const int slot = ((yd % TH_RING) + TH_RING) % TH_RING;
+      for (int idx = tid; idx < a.N * TH_PX; idx += NTHREADS) {
+        const int cls = idx >> 7, x = idx & 127;
+        float* o = Os + (slot * 4 + cls) * TH_PX + x;
+        const float v = *o;
+        *o = 0.f;
+        const int xg = x0 + x;
+        if (yd >= y0 && yd < yend && x < wout && xg < a.W) a.logits[(((size_t)b * a.N + cls) * a.H + yd) * a.W + xg] = v;
+      }
+    }
+    if (it < nsteps && xl < wout) {
+      // taps come grouped by dy (row-major tap tables): sum a group in registers, one LDS atomic per (group, class)
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      int cur = a.dy[tbeg];
+      for (int tp = tbeg; tp < tend; ++tp) {
+        const int dyt = a.dy[tp];
+        if (dyt != cur) {
+          const int yo = iy - cur;
+          const int slot = ((yo % TH_RING) + TH_RING) % TH_RING;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < a.N) { atomicAdd(Os + (slot * 4 + c) * TH_PX + xl, sum[c]); sum[c] = 0.f; }
+          cur = dyt;
+        }
+        const float* pp = Ps + (tp * a.N) * TH_PP + xl + R + a.dx[tp];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < a.N) sum[c] += pp[c * TH_PP];
+      }
+      const int yo = iy - cur;
+      const int slot = ((yo % TH_RING) + TH_RING) % TH_RING;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < a.N) atomicAdd(Os + (slot * 4 + c) * TH_PX + xl, sum[c]);
+    }
+  }
+}
+
+static bool g_no_thin = false;
+void thin_set_enabled(bool on) { g_no_thin = !on; }
+
+// Returns hipErrorNotSupported when the layer is not eligible.
+hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t st) {
+  if (g_no_thin || dtype != DT_F16 || epi != EPI_LOGITS || c.nseg != 1) return hipErrorNotSupported;
+  const Seg& sg = c.seg[0];
+  if (sg.mode != G_PLAIN || sg.istride != 1 || sg.Hs != c.Ho || sg.Ws != c.Wo || c.ostride != 1 || c.py != 0 || c.px != 0 ||
+      c.Hout != c.Ho || c.Wout != c.Wo)
+    return hipErrorNotSupported;
+  if (sg.C != 64 || sg.Cpad != 64 || sg.scale == nullptr || sg.q != nullptr) return hipErrorNotSupported;
+  if (c.N < 1 || c.N > 4 || sg.ntaps > TH_MAXTAPS || sg.ntaps * c.N > TH_COLS) return hipErrorNotSupported;
+  ThinArgs a;
+  a.src = (const f16*)sg.src; a.ld = sg.ld; a.B = c.B; a.H = c.Ho; a.W = c.Wo;
+  a.scale = sg.scale; a.shift = sg.shift;
+  a.wpack = (const f16*)c.wpack; a.Npad = c.Npad; a.N = c.N; a.ntaps = sg.ntaps;
+  a.logits = c.logits;
+  int R = 0, prev = -128;
+  for (int t = 0; t < sg.ntaps; ++t) {
+    const int dy = (int)(signed char)(sg.taps[t] & 0xff), dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff);
+    if (dy < prev) return hipErrorNotSupported;  // the reduction wants taps grouped by dy
+    prev = dy;
+    a.dy[t] = (signed char)dy; a.dx[t] = (signed char)dx;
+    R = std::max(R, std::max(abs(dy), abs(dx)));
+  }
+  if (R > 2) return hipErrorNotSupported;  // ring of 2R+2 <= TH_RING rows
+  a.R = R;
+  const int wout = TH_PX - 2 * R;
+  a.nxs = (a.W + wout - 1) / wout;
+  a.rows_per_wg = 64;
+  while (a.rows_per_wg > 8 && (long)a.B * ((a.H + a.rows_per_wg - 1) / a.rows_per_wg) * a.nxs < 1024) a.rows_per_wg /= 2;
+  a.nys = (a.H + a.rows_per_wg - 1) / a.rows_per_wg;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)thin_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ThinSmem::bytes);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(thin_logits_kernel, dim3(a.B * a.nys * a.nxs), dim3(NTHREADS), ThinSmem::bytes, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace dmm

@@ -67,6 +67,10 @@ typedef struct dmm_plan dmm_plan;
 
 const char* dmm_last_error(void);
 int dmm_version(void);
+/* Kernel selection switches for tests and A/B timing: "thin_logits" (1 = gather-once kernel for the heat-map head's last
+ * convolution, 0 = generic kernels).  Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the
+ * fp32 summation order. */
+int dmm_set_option(const char* name, int value);
 
 /* Plan construction needs no GPU: it derives the layer table, the state_dict layout and the workspace size. */
 int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out);

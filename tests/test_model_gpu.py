@@ -269,3 +269,30 @@ def test_full_size_c2_step_properties():
         model(rgb, lidar)
     met2 = model.loss_backward(tgt)
     assert _rel(met2["loss_per_class"], loss1) < 1e-6
+
+
+@pytest.mark.gpu
+def test_thin_logits_kernel_matches_generic_kernels():
+    """The gather-once kernel of the 5x5 head conv (thin.hip) against the generic implicit-GEMM path on the same fp16 tensors:
+    identical operands, only the fp32 summation order differs."""
+    import torch
+    from dmmfods_amd import _lib
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import densenet121_u_lidar
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    cfg = get_config("/tmp/none")
+    model = densenet121_u_lidar(config=cfg, compute_dtype="fp16").cuda().train()
+    g = torch.Generator().manual_seed(5)
+    for (H, W) in ((64, 96), (160, 288)):      # one x strip / three x strips with a ragged last one, several y strips
+        rgb = (torch.rand(2, 3, H, W, generator=g) * 255).cuda()
+        lidar = (torch.rand(2, 1, H, W, generator=g) * 80).cuda()
+        out = {}
+        for on in (1, 0):
+            _lib.check(_lib.lib().dmm_set_option(b"thin_logits", on))
+            with torch.no_grad():
+                out[on] = model(rgb, lidar).clone()
+        _lib.check(_lib.lib().dmm_set_option(b"thin_logits", 1))
+        scale = float(out[0].abs().max())
+        assert scale > 0 and torch.isfinite(out[1]).all()
+        assert float((out[1] - out[0]).abs().max()) <= 1e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().dmm_set_option(b"no_such_option", 1))
