@@ -13,6 +13,7 @@
 // 16-bit storage only; fp32 tensors stay on the generic kernels (the parity configuration).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gather.h"
@@ -44,6 +45,9 @@ struct ThinSmem {
   static constexpr int bytes = A_BYTES + P_BYTES + O_BYTES;
 };
 
+// KR, KN: tap radius and class count at compile time (full row-major (2KR+1)^2 tap table), so that the reduction is
+// straight-line code with immediate LDS offsets.
+template <int KR, int KN>
 __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
@@ -55,10 +59,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
   const int xs = bid % a.nxs; bid /= a.nxs;
   const int ys = bid % a.nys;
   const int b = bid / a.nys;
-  const int R = a.R;
+  constexpr int R = KR;
+  constexpr int KW5 = 2 * KR + 1;
   const int wout = TH_PX - 2 * R;  // output columns per strip
   const int x0 = xs * wout, y0 = ys * a.rows_per_wg;
-  const int ncols = a.ntaps * a.N;
+  constexpr int ncols = KW5 * KW5 * KN;
 
   // ---- gather role: slot column j (8 channels), pixels pg + 32 i ----
   const int j = tid & 7, pg = tid >> 3;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int col = 32 * t + r;
-    const int tap = col / a.N, cls = col - tap * a.N;
+    const int tap = col / KN, cls = col - tap * KN;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -92,10 +97,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
       }
   }
 
-  // ---- reduce role: output column xl, taps [tbeg, tend) ----
+  // ---- reduce role: output column xl, (dy, class) groups [half * GH, ...) - every ring element has ONE owner thread ----
   const int xl = tid & 127, half = tid >> 7;
-  const int tmid = (a.ntaps + 1) / 2;
-  const int tbeg = half ? tmid : 0, tend = half ? a.ntaps : tmid;
+  constexpr int NG = KW5 * KN, GH = (NG + 1) / 2;
 
   for (int i = tid; i < TH_RING * 4 * TH_PX; i += NTHREADS) Os[i] = 0.f;
 
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
   const int nsteps = a.rows_per_wg + 2 * R;
   const int yend = min(a.H, y0 + a.rows_per_wg);
   issue(y0 - R);
+  int s_lo = (((y0 - 2 * R - 1) % TH_RING) + TH_RING) % TH_RING;  // ring slot of output row iy - R - 1 (the row written out)
   __syncthreads();  // ring cleared
   for (int it = 0; it <= nsteps; ++it) {
     const int iy = y0 - R + it;  // input row of this step (it == nsteps: drain, only writes the last output row)
@@ -161,41 +166,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
     // write out the row completed by the previous step and clear its slot (no tap of this step lands there)
     {
       const int yd = iy - 1 - R;
-      const int slot = ((yd % TH_RING) + TH_RING) % TH_RING;
-      for (int idx = tid; idx < a.N * TH_PX; idx += NTHREADS) {
+      for (int idx = tid; idx < KN * TH_PX; idx += NTHREADS) {
         const int cls = idx >> 7, x = idx & 127;
-        float* o = Os + (slot * 4 + cls) * TH_PX + x;
+        float* o = Os + (s_lo * 4 + cls) * TH_PX + x;
         const float v = *o;
         *o = 0.f;
         const int xg = x0 + x;
-        if (yd >= y0 && yd < yend && x < wout && xg < a.W) a.logits[(((size_t)b * a.N + cls) * a.H + yd) * a.W + xg] = v;
+        if (yd >= y0 && yd < yend && x < wout && xg < a.W) a.logits[(((size_t)b * KN + cls) * a.H + yd) * a.W + xg] = v;
       }
     }
     if (it < nsteps && xl < wout) {
-      // taps come grouped by dy (row-major tap tables): sum a group in registers, one LDS atomic per (group, class)
-      float sum[4] = {0.f, 0.f, 0.f, 0.f};
-      int cur = a.dy[tbeg];
-      for (int tp = tbeg; tp < tend; ++tp) {
-        const int dyt = a.dy[tp];
-        if (dyt != cur) {
-          const int yo = iy - cur;
-          const int slot = ((yo % TH_RING) + TH_RING) % TH_RING;
+      // group g = (dyi, cls): output row iy - (dyi - R) = (iy - R - 1) + (2R + 1 - dyi), i.e. ring slot s_lo + 2R + 1 - dyi
+      auto reduce = [&](auto G0) {
+        constexpr int g0 = decltype(G0)::value;
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c < a.N) { atomicAdd(Os + (slot * 4 + c) * TH_PX + xl, sum[c]); sum[c] = 0.f; }
-          cur = dyt;
+        for (int g = g0; g < g0 + GH && g < NG; ++g) {
+          const int dyi = g / KN, cls = g % KN;
+          float sum = 0.f;
+#pragma unroll
+          for (int dxi = 0; dxi < KW5; ++dxi) sum += Ps[((dyi * KW5 + dxi) * KN + cls) * TH_PP + xl + dxi];
+          int slot = s_lo + 2 * R + 1 - dyi;
+          if (slot >= TH_RING) slot -= TH_RING;
+          Os[(slot * 4 + cls) * TH_PX + xl] += sum;
         }
-        const float* pp = Ps + (tp * a.N) * TH_PP + xl + R + a.dx[tp];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < a.N) sum[c] += pp[c * TH_PP];
-      }
-      const int yo = iy - cur;
-      const int slot = ((yo % TH_RING) + TH_RING) % TH_RING;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < a.N) atomicAdd(Os + (slot * 4 + c) * TH_PX + xl, sum[c]);
+      };
+      if (half == 0) reduce(std::integral_constant<int, 0>());
+      else reduce(std::integral_constant<int, GH>());
     }
+    if (++s_lo == TH_RING) s_lo = 0;
   }
 }
 
@@ -216,28 +214,34 @@ hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t
   a.scale = sg.scale; a.shift = sg.shift;
   a.wpack = (const f16*)c.wpack; a.Npad = c.Npad; a.N = c.N; a.ntaps = sg.ntaps;
   a.logits = c.logits;
-  int R = 0, prev = -128;
+  // the kernel wants the full row-major (2R+1)^2 tap table
+  int R = 0;
+  for (int t = 0; t < sg.ntaps; ++t) R = std::max(R, abs((int)(signed char)(sg.taps[t] & 0xff)));
+  const int kw = 2 * R + 1;
+  if (sg.ntaps != kw * kw) return hipErrorNotSupported;
   for (int t = 0; t < sg.ntaps; ++t) {
     const int dy = (int)(signed char)(sg.taps[t] & 0xff), dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff);
-    if (dy < prev) return hipErrorNotSupported;  // the reduction wants taps grouped by dy
-    prev = dy;
+    if (dy != t / kw - R || dx != t % kw - R) return hipErrorNotSupported;
     a.dy[t] = (signed char)dy; a.dx[t] = (signed char)dx;
-    R = std::max(R, std::max(abs(dy), abs(dx)));
   }
-  if (R > 2) return hipErrorNotSupported;  // ring of 2R+2 <= TH_RING rows
+  void (*kern)(const ThinArgs) = nullptr;
+  if (R == 2 && c.N == 3) kern = thin_logits_kernel<2, 3>;
+  else if (R == 2 && c.N == 1) kern = thin_logits_kernel<2, 1>;
+  else if (R == 2 && c.N == 2) kern = thin_logits_kernel<2, 2>;
+  if (kern == nullptr) return hipErrorNotSupported;
   a.R = R;
   const int wout = TH_PX - 2 * R;
   a.nxs = (a.W + wout - 1) / wout;
   a.rows_per_wg = 64;
   while (a.rows_per_wg > 8 && (long)a.B * ((a.H + a.rows_per_wg - 1) / a.rows_per_wg) * a.nxs < 1024) a.rows_per_wg /= 2;
   a.nys = (a.H + a.rows_per_wg - 1) / a.rows_per_wg;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)thin_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ThinSmem::bytes);
+  static const void* attr = nullptr;
+  if (attr != (const void*)kern) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ThinSmem::bytes);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr = (const void*)kern;
   }
-  hipLaunchKernelGGL(thin_logits_kernel, dim3(a.B * a.nys * a.nxs), dim3(NTHREADS), ThinSmem::bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nys * a.nxs), dim3(NTHREADS), ThinSmem::bytes, st, a);
   return hipGetLastError();
 }
 
