@@ -80,7 +80,26 @@ def collect_profile(model, plan, K, ops_out=None):
     return classes
 
 
-def roofline_block(classes, dtype):
+def measured_traffic(cls, workload):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py); bench.py cannot run the profiler around itself, so the figure comes from profiles/ and is only
+    used when it was collected on the same workload."""
+    import glob
+    import json as _json
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "*pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = _json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if (d.get("config"), d.get("batch"), d.get("dtype")) != workload:
+            continue
+        e = d.get("classes", {}).get(cls)
+        if e:
+            return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    return None
+
+
+def roofline_block(classes, dtype, workload=None):
     if not classes:
         return None, None
     peak_f = PEAK_MFMA_TFLOPS[dtype] * 1e12
@@ -107,6 +126,9 @@ def roofline_block(classes, dtype):
         roof = dict(bound="hbm", achieved=round(e["bytes"] / t / 1e9, 2), peak=PEAK_HBM_GBS, unit="GB/s")
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["traffic"] = None
+    tr = measured_traffic(cls, workload)
+    if tr is not None:
+        roof["traffic"], roof["traffic_source"] = tr
     roof["kernel"] = cls
     roof["avg_launch_ms"] = round(e["ms"] / max(e["launches"], 1), 4)
     roof["alg_flops_per_launch"] = e["flops"] / max(e["launches"], 1)
@@ -222,7 +244,7 @@ def main():
         roof, table = (None, None)
         if not args.no_profile:
             ops_list = [] if args.ops else None
-            roof, table = roofline_block(collect_profile(model, plan, args.steps, ops_list), c["dtype"])
+            roof, table = roofline_block(collect_profile(model, plan, args.steps, ops_list), c["dtype"], (args.config, c["batch"], "f16" if c["dtype"] in ("fp16", "f16", "float16") else "f32"))
             if ops_list:
                 ops_list.sort(reverse=True)
                 for ms_, lab, fl, by in ops_list[:args.ops]:
