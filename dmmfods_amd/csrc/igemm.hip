@@ -32,7 +32,12 @@ template <> struct Mma<float> {
   }
 };
 
-constexpr int KS = 2;  // K-chunks per pipeline stage: twice the bytes in flight and twice the MFMAs per barrier
+// K-chunks per pipeline stage: 2 = twice the bytes in flight and twice the MFMAs per barrier; 1 = half the LDS, which lets
+// a third workgroup of the 128-column variants onto a CU
+#ifndef IGEMM_KS128
+#define IGEMM_KS128 2
+#endif
+constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
 #ifndef IGEMM_ADIST
 #define IGEMM_ADIST 1
 #endif
@@ -44,6 +49,7 @@ constexpr int ADIST = IGEMM_ADIST;  // register prefetch distance of the gathere
 template <typename T, int BN>
 struct IgemmSmem {
   static constexpr int SLOT = TT<T>::SLOT;
+  static constexpr int KS = ks_for(BN);
   static constexpr int A_BYTES = KS * BM * ROWB;
   static constexpr int B_BYTES = KS * BN * ROWB;
   static constexpr int STAGE_PITCH_T = BN + SLOT;  // elements of T
@@ -90,7 +96,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   typedef typename TT<T>::vec V;
   typedef IgemmSmem<T, BN> SM;
   constexpr int NT = BN / 32;
-  constexpr int NB = BN / 32;  // 1-KiB LDS-DMA pieces of the B image per wave per stage
+  constexpr int KS = ks_for(BN);
+  constexpr int NB = KS * BN / 64;  // 1-KiB LDS-DMA pieces of the B image per wave per stage
+  constexpr int NR = 2 * KS;        // rows per thread
+  constexpr int RST = 64 / KS;      // row groups; a thread owns rows rg + RST i
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAINB = (SM::MAIN > (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F)) ? SM::MAIN
@@ -112,9 +121,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int mtile = lbid / ntiles, ntile = lbid - mtile * ntiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
 
-  const int u = tid >> 7;          // chunk of the stage this thread gathers (wave-uniform)
+  const int u = KS == 2 ? (tid >> 7) : 0;  // chunk of the stage this thread gathers (wave-uniform)
   const int j = tid & 3;           // slot column
-  const int rg = (tid >> 2) & 31;  // rows rg + 32 i
+  const int rg = (tid >> 2) & (RST - 1);  // rows rg + RST i
 
   if (tid < BM) {
     const int m = m0 + tid;
@@ -154,18 +163,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const SegU su0 = seg_uniform(a.seg[0]);
   const SegU su1 = seg_uniform(a.seg[a.nseg > 1 ? 1 : 0]);
 
-  int rb[4], ry[4], rx[4];
-  bool rv[4];
-  size_t roff[4], roff2[4];
+  int rb[NR], ry[NR], rx[NR];
+  bool rv[NR];
+  size_t roff[NR], roff2[NR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     if constexpr (LIN) {
-      const int m = m0 + rg + 32 * i;
+      const int m = m0 + rg + RST * i;
       rv[i] = m < a.M;
       roff[i] = (size_t)(rv[i] ? m : 0) * su0.ld;
       roff2[i] = (size_t)(rv[i] ? m : 0) * su0.ld2;
     } else {
-      const int4 ri = rowinfo[rg + 32 * i];
+      const int4 ri = rowinfo[rg + RST * i];
       rb[i] = ri.x; ry[i] = ri.y; rx[i] = ri.z; rv[i] = ri.w != 0;
     }
   }
@@ -176,12 +185,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // B: per-lane source offsets of this wave's LDS-DMA pieces (fixed over K)
+  // B: per-lane source offsets of this wave's LDS-DMA pieces (fixed over K); piece p covers 16 weight rows of chunk ub
   const T* wp = (const T*)a.wpack;
+  constexpr int PPC = BN / 16;  // pieces per chunk
+  const int ub = (wave * NB) / PPC;
   int boff[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    const int nn = ((wave & 1) * NB + q) * 16 + (lane >> 2);
+    const int nn = ((wave * NB + q) % PPC) * 16 + (lane >> 2);
     const int sl = (lane & 3) ^ ((nn >> 2) & 3);
     boff[q] = (n0 + nn) * BK + sl * SLOT;
   }
@@ -190,25 +201,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   // deferred-gradient correction) runs in store_a ADIST iterations later, behind the MFMAs of the steps in between.  With
   // ADIST = 2 two register sets alternate, so a step's loads have a whole iteration (not just one MFMA block) to land.
   struct ARing {
-    RawSlot<T> raw[4];
+    RawSlot<T> raw[NR];
     int s, c, narr;
   };
   ARing R0, R1;
   auto issue_b = [&](int buf, int stage) {  // weights: LDS-DMA (a dead chunk re-reads chunk 0: its A slots are zero)
-    const int g = stage * KS + u;
+    const int g = stage * KS + ub;
     const T* bsrc = wp + (size_t)(g < total ? g : 0) * a.Npad * BK;
-    unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + u * BN * ROWB + (wave & 1) * NB * 1024;
+    unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + wave * NB * 1024;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
       if (!(IGEMM_DBG & 8)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff[q]),
                                        (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
   };
   auto issue_a = [&](ARing& R, int stage) {
-    RawSlot<T>(&araw)[4] = R.raw;
+    RawSlot<T>(&araw)[NR] = R.raw;
     const int g = stage * KS + u;
     const bool live = g < total;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
 #pragma unroll
       for (int e = 0; e < SLOT; ++e) { araw[i].v[e] = (T)0; araw[i].v2[e] = (T)0; }
       araw[i].state = 0;
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       const bool cv = live && c < su0.C;
       R.s = 0; R.c = c; R.narr = cv ? su0.narr : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         if (cv && rv[i]) {
           if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su0.src + roff[i] + c);
           if (!(IGEMM_DBG & 1) && (PRO == 2 || (PRO < 0 && su0.narr == 4))) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + c);
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       const Seg& sg = a.seg[R.s];
       const SlotK<SLOT> kpool = lds_slot_consts<SLOT>(s1 ? lk1 : lk0, su.C, R.narr, c);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         if (inside && rv[i]) {
           araw[i].v = gather_slot<T, true>(sg, rb[i], ry[i], rx[i], true, 0, c, kpool);
           araw[i].state = 2;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     const unsigned hl = (unsigned)su.Hs << up, wl = (unsigned)su.Ws << up;
     const bool two = PRO == 2 || (PRO < 0 && su.narr == 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int sy = ry[i] * su.istride + dy, sx = rx[i] * su.istride + dx;
       if (inside && rv[i] && (unsigned)sy < hl && (unsigned)sx < wl) {
         const size_t pix = (size_t)((rb[i] * su.Hs + (sy >> up)) * su.Ws + (sx >> up));
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     if constexpr (PRO >= 0) kk = lds_slot_consts_n<SLOT, PRO == 1 ? 2 : (PRO == 2 ? (sizeof(T) == 2 ? 2 : 4) : 0)>(lk, cst, R.c);
     else kk = lds_slot_consts<SLOT>(lk, cst, R.narr, R.c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = u * BM + rg + 32 * i;
+    for (int i = 0; i < NR; ++i) {
+      const int row = u * BM + rg + RST * i;
       *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = (IGEMM_DBG & 2) ? R.raw[i].v : finish_slot<T, PRO>(R.narr, R.raw[i], kk);
     }
   };

@@ -418,7 +418,8 @@ hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st) 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pack: one thread per (chunk, n) row of BK elements.  unpack: the same enumeration run backwards.
+// pack: one thread per 16-byte slot of a (chunk, n) row (adjacent lanes write adjacent slots: full-line stores).
+// unpack: the same enumeration run backwards.
 __device__ __forceinline__ bool pack_locate(const PackDesc& d, int chunk, int kk, int BK, int& seg, int& tap, int& ch) {
   int s = 0, lc = chunk;
   while (s < d.nseg && lc >= d.seg[s].nchunks) { lc -= d.seg[s].nchunks; ++s; }
@@ -432,8 +433,9 @@ __device__ __forceinline__ bool pack_locate(const PackDesc& d, int chunk, int kk
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, const int* row_prefix, int ndesc, int total_rows) {
-  constexpr int BK = 4 * TT<T>::SLOT;
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int SLOT = TT<T>::SLOT, BK = 4 * SLOT;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 2, sl = gid & 3;
   if (row >= total_rows) return;
   int lo = 0, hi = ndesc - 1;  // last desc with row_prefix[desc] <= row
   while (lo < hi) {
@@ -443,8 +445,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, const 
   const PackDesc& d = descs[lo];
   const int lr = row - row_prefix[lo];
   const int chunk = lr / d.Npad, n = lr - chunk * d.Npad;
-  T* dst = (T*)d.dst + ((size_t)chunk * d.Npad + n) * BK;
-  for (int kk = 0; kk < BK; ++kk) {
+  T* dst = (T*)d.dst + ((size_t)chunk * d.Npad + n) * BK + sl * SLOT;
+  float out[SLOT];
+#pragma unroll
+  for (int e = 0; e < SLOT; ++e) {
+    const int kk = sl * SLOT + e;
     int s, tap, ch;
     float v = 0.f;
     if (n < d.N && pack_locate(d, chunk, kk, BK, s, tap, ch)) {
@@ -456,15 +461,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, const 
         if (mt != 0xff) v += d.w[base + (size_t)mt * d.st];
       }
     }
-    dst[kk] = from_f32<T>(v);
+    out[e] = v;
   }
+  *(typename TT<T>::vec*)dst = f32_to_vec<T>(out);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* descs, const int* row_prefix, int ndesc, int total_rows,
                                                      float grad_scale) {
-  constexpr int BK = 4 * TT<T>::SLOT;
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int SLOT = TT<T>::SLOT, BK = 4 * SLOT;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 2, sl = gid & 3;
   if (row >= total_rows) return;
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
@@ -476,11 +483,15 @@ __global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* descs, cons
   const int lr = row - row_prefix[lo];
   const int chunk = lr / d.Npad, n = lr - chunk * d.Npad;
   if (n >= d.N) return;
-  const float* src = d.dpack + ((size_t)chunk * d.Npad + n) * BK;
-  for (int kk = 0; kk < BK; ++kk) {
+  const float* src = d.dpack + ((size_t)chunk * d.Npad + n) * BK + sl * SLOT;
+  float in[SLOT];
+  load_f32s<SLOT>(src, in);
+#pragma unroll
+  for (int e = 0; e < SLOT; ++e) {
+    const int kk = sl * SLOT + e;
     int s, tap, ch;
     if (!pack_locate(d, chunk, kk, BK, s, tap, ch)) continue;
-    const float v = src[kk] * grad_scale;
+    const float v = in[e] * grad_scale;
     const unsigned tw = d.seg[s].tapw[tap];
     const size_t base = (size_t)n * d.sn + (size_t)(d.seg[s].koff + ch) * d.sk;
     const bool merged = ((tw >> 8) & 0xff) != 0xff;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* descs, cons
 
 hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st) {
   if (total_rows <= 0) return hipSuccess;
-  dim3 grid((total_rows + 255) / 256), block(256);
+  dim3 grid((total_rows * 4 + 255) / 256), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(pack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
   else hipLaunchKernelGGL(pack_kernel<float>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
   return hipGetLastError();
@@ -505,7 +516,7 @@ hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int nde
 hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
                          hipStream_t st) {
   if (total_rows <= 0) return hipSuccess;
-  dim3 grid((total_rows + 255) / 256), block(256);
+  dim3 grid((total_rows * 4 + 255) / 256), block(256);
   if (dtype == DT_F16)
     hipLaunchKernelGGL(unpack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows, grad_scale);
   else
