@@ -75,6 +75,8 @@ def lib():
     L.dmm_plan_backward.argtypes = [vp, vp, vp]
     L.dmm_plan_loss_metrics.argtypes = [vp, vp, vp, vp, vp]
     L.dmm_plan_profile_begin.argtypes = [vp, C.c_int]
+    L.dmm_plan_profile_filter.restype = C.c_int
+    L.dmm_plan_profile_filter.argtypes = [vp, C.c_char_p]
     L.dmm_plan_profile_num_ops.argtypes = [vp, C.c_int]
     L.dmm_plan_profile_op.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dmm_plan_profile_collect.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
@@ -92,7 +94,7 @@ EXPORTS = [
     "dmm_last_error", "dmm_version", "dmm_set_option", "dmm_plan_create", "dmm_plan_destroy", "dmm_plan_num_tensors",
     "dmm_plan_tensor_info", "dmm_plan_num_params", "dmm_plan_num_buffer_elems", "dmm_plan_workspace_bytes",
     "dmm_plan_forward_flops", "dmm_plan_bind", "dmm_plan_forward", "dmm_plan_loss_backward", "dmm_plan_backward",
-    "dmm_plan_loss_metrics", "dmm_plan_profile_begin", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
+    "dmm_plan_loss_metrics", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
     "dmm_conv_dgrad",
 ]

@@ -1,6 +1,7 @@
 // extern "C" surface of libdmmfods_hip.so (see include/dmmfods_hip.h) and the launch-list executor.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -23,6 +24,8 @@ static int fail(int code, const std::string& msg) {
     if (e__ != hipSuccess) return fail(DMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+static bool g_overlap_wgrad = getenv("DMM_NO_OVERLAP") == nullptr;
+
 extern "C" {
 
 const char* dmm_last_error(void) { return g_err.c_str(); }
@@ -30,6 +33,7 @@ int dmm_version(void) { return 100; }
 
 int dmm_set_option(const char* name, int value) {
   if (!name) return fail(DMM_ERR_INVALID, "null argument");
+  if (std::string(name) == "overlap_wgrad") { g_overlap_wgrad = value != 0; return DMM_OK; }
   if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
   return fail(DMM_ERR_INVALID, std::string("unknown option ") + name);
 }
@@ -55,7 +59,13 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   return DMM_OK;
 }
 
-void dmm_plan_destroy(dmm_plan* plan) { delete plan; }
+void dmm_plan_destroy(dmm_plan* plan) {
+  if (!plan) return;
+  for (void* e : plan->fork_events) hipEventDestroy((hipEvent_t)e);
+  if (plan->join_event) hipEventDestroy((hipEvent_t)plan->join_event);
+  if (plan->side_stream) hipStreamDestroy((hipStream_t)plan->side_stream);
+  delete plan;
+}
 
 int dmm_plan_num_tensors(const dmm_plan* plan) { return plan ? (int)plan->tensors.size() : 0; }
 
@@ -104,17 +114,67 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     const int pass = p->prof_pass[prof_which]++;
     if ((int)sets.size() <= pass) sets.resize(pass + 1);
     evs = &sets[pass];
-    const size_t need = ops.size() + ev_offset + 1;
+    const size_t need = 2 * (ops.size() + ev_offset);
     while (evs->size() < need) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
       evs->push_back((void*)e);
     }
-    hipEventRecord((hipEvent_t)(*evs)[ev_offset], st);
   }
+  const std::string& filt = p->prof_filter;
+  auto selected = [&](const Op& o) { return evs != nullptr && (filt.empty() || strncmp(o.label, filt.c_str(), filt.size()) == 0); };
+  // Overlap: a weight gradient only needs what the ops before it produced, and nothing but the final unpack reads it, so
+  // it goes to a low-priority side stream (fork event before, one join before unpack).  Late layers launch a few hundred
+  // workgroups of a few microseconds; two independent chains fill the CUs that one chain leaves idle.  Per-op profiling keeps
+  // everything on one stream so that the event pairs bracket each kernel alone; a FILTERED profile (one kernel class) runs
+  // as in production.
+  const bool overlap = g_overlap_wgrad && (evs == nullptr || !filt.empty());
+  hipStream_t side = nullptr;
+  size_t nfork = 0;
+  bool forked = false;
+  if (overlap) {
+    if (!p->side_stream) {
+      int lo = 0, hi = 0;
+      hipDeviceGetStreamPriorityRange(&lo, &hi);
+      hipStream_t s2;
+      if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
+      hipEvent_t je;
+      if (hipEventCreateWithFlags(&je, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+      p->side_stream = (void*)s2;
+      p->join_event = (void*)je;
+    }
+    side = (hipStream_t)p->side_stream;
+  }
+  auto join = [&]() {
+    if (forked) {
+      hipEventRecord((hipEvent_t)p->join_event, side);
+      hipStreamWaitEvent(st, (hipEvent_t)p->join_event, 0);
+      forked = false;
+    }
+  };
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& o = ops[i];
     hipError_t e = hipSuccess;
+    if (overlap && o.kind == OP_WGRAD) {
+      if (nfork >= p->fork_events.size()) {
+        hipEvent_t fe;
+        if (hipEventCreateWithFlags(&fe, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+        p->fork_events.push_back((void*)fe);
+      }
+      hipEvent_t fe = (hipEvent_t)p->fork_events[nfork++];
+      hipEventRecord(fe, st);
+      hipStreamWaitEvent(side, fe, 0);
+      const bool sel = selected(o);
+      if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], side);
+      e = launch_wgrad(o.w, dt, mfma, side);
+      if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], side);
+      forked = true;
+      if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " (wgrad, side stream): " + hipGetErrorString(e));
+      continue;
+    }
+    if (o.kind == OP_UNPACK) join();
+    const bool sel = selected(o);
+    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], st);
     switch (o.kind) {
       case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, st); break;
       case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, st); break;
@@ -132,8 +192,9 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       default: return fail(DMM_ERR_STATE, "unknown op");
     }
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
-    if (evs) hipEventRecord((hipEvent_t)(*evs)[ev_offset + i + 1], st);
+    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], st);
   }
+  join();
   return DMM_OK;
 }
 
@@ -186,6 +247,12 @@ int dmm_plan_profile_begin(dmm_plan* plan, int max_passes) {
   return DMM_OK;
 }
 
+int dmm_plan_profile_filter(dmm_plan* plan, const char* label_prefix) {
+  if (!plan) return fail(DMM_ERR_INVALID, "null plan");
+  plan->prof_filter = label_prefix ? label_prefix : "";
+  return DMM_OK;
+}
+
 int dmm_plan_profile_num_ops(const dmm_plan* plan, int which) {
   if (!plan || which < 0 || which > 1) return 0;
   return (int)(which == 0 ? plan->fwd_train.size() : plan->bwd.size());
@@ -209,10 +276,13 @@ int dmm_plan_profile_collect(dmm_plan* plan, int which, double* ms_sum, int n, i
   for (int i = 0; i < nops; ++i) ms_sum[i] = 0;
   int np = 0;
   for (auto& evs : plan->prof_events[which]) {
-    if ((int)evs.size() < nops + 1 || np >= plan->prof_pass[which]) continue;
+    if ((int)evs.size() < 2 * nops || np >= plan->prof_pass[which]) continue;
+    const std::vector<Op>& ops = which == 0 ? plan->fwd_train : plan->bwd;
+    const std::string& filt = plan->prof_filter;
     for (int i = 0; i < nops; ++i) {
+      if (!filt.empty() && strncmp(ops[i].label, filt.c_str(), filt.size()) != 0) continue;
       float ms = 0;
-      if (hipEventElapsedTime(&ms, (hipEvent_t)evs[i], (hipEvent_t)evs[i + 1]) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventElapsedTime failed");
+      if (hipEventElapsedTime(&ms, (hipEvent_t)evs[2 * i], (hipEvent_t)evs[2 * i + 1]) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventElapsedTime failed");
       ms_sum[i] += ms;
     }
     ++np;

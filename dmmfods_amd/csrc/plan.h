@@ -87,5 +87,10 @@ struct dmm_plan {
   // profiling: per-op events on the launch stream, one set per recorded pass
   int prof_max_passes = 0;
   int prof_pass[2] = {0, 0};                       // passes recorded for [0] training forward, [1] backward
-  std::vector<std::vector<void*>> prof_events[2];  // [which][pass] -> nops+1 events
+  std::vector<std::vector<void*>> prof_events[2];  // [which][pass] -> one (start, end) event pair per op
+  std::string prof_filter;                         // only ops whose label starts with this are bracketed (empty: all)
+  // weight-gradient GEMMs run on a second stream beside the data-gradient chain (nothing reads them before unpack)
+  void* side_stream = nullptr;
+  std::vector<void*> fork_events;
+  void* join_event = nullptr;
 };

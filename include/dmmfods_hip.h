@@ -68,8 +68,9 @@ typedef struct dmm_plan dmm_plan;
 const char* dmm_last_error(void);
 int dmm_version(void);
 /* Kernel selection switches for tests and A/B timing: "thin_logits" (1 = gather-once kernel for the heat-map head's last
- * convolution, 0 = generic kernels).  Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the
- * fp32 summation order. */
+ * convolution, 0 = generic kernels), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the data-gradient
+ * chain, 0 = one stream).  Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32 summation
+ * order. */
 int dmm_set_option(const char* name, int value);
 
 /* Plan construction needs no GPU: it derives the layer table, the state_dict layout and the workspace size. */
@@ -107,8 +108,13 @@ int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream);
 
 /* Per-launch timing with HIP events recorded on the launch stream (used by bench.py for the roofline block).
  * which: 0 = training forward, 1 = loss + backward.  profile_begin(plan, n) arms recording for the next n passes of
- * each; profile_collect sums per-op milliseconds over the recorded passes (synchronise the stream first). */
+ * each; profile_collect sums per-op milliseconds over the recorded passes (synchronise the stream first).
+ * profile_filter(plan, "igemm.bnbwd.n128/") restricts the event pairs to the launches whose label starts with the prefix
+ * (NULL or "" = every launch).  Unfiltered profiling serialises everything on one stream so that each pair brackets one
+ * kernel alone; a filtered profile runs exactly as in production (weight gradients on the side stream) and costs two
+ * event records per selected launch. */
 int dmm_plan_profile_begin(dmm_plan* plan, int max_passes);
+int dmm_plan_profile_filter(dmm_plan* plan, const char* label_prefix);
 int dmm_plan_profile_num_ops(const dmm_plan* plan, int which);
 int dmm_plan_profile_op(const dmm_plan* plan, int which, int index, const char** label, double* flops, double* bytes);
 int dmm_plan_profile_collect(dmm_plan* plan, int which, double* ms_sum, int n, int* passes);
