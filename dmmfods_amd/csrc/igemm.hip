@@ -46,10 +46,10 @@ constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
 #endif
 constexpr int ADIST = IGEMM_ADIST;  // register prefetch distance of the gathered operand, in stages (1 or 2)
 
-template <typename T, int BN>
+template <typename T, int BN, int KSV>
 struct IgemmSmem {
   static constexpr int SLOT = TT<T>::SLOT;
-  static constexpr int KS = ks_for(BN);
+  static constexpr int KS = KSV;
   static constexpr int A_BYTES = KS * BM * ROWB;
   static constexpr int B_BYTES = KS * BN * ROWB;
   static constexpr int STAGE_PITCH_T = BN + SLOT;  // elements of T
@@ -89,14 +89,14 @@ __device__ __forceinline__ SegU seg_uniform(const Seg& sg) {
   return r;
 }
 
-template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO>
+template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO, int KSV>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
   typedef typename TT<T>::vec V;
-  typedef IgemmSmem<T, BN> SM;
+  typedef IgemmSmem<T, BN, KSV> SM;
   constexpr int NT = BN / 32;
-  constexpr int KS = ks_for(BN);
+  constexpr int KS = KSV;
   constexpr int NB = KS * BN / 64;  // 1-KiB LDS-DMA pieces of the B image per wave per stage
   constexpr int NR = 2 * KS;        // rows per thread
   constexpr int RST = 64 / KS;      // row groups; a thread owns rows rg + RST i
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   const int mtile = lbid / ntiles, ntile = lbid - mtile * ntiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
 
-  const int u = KS == 2 ? (tid >> 7) : 0;  // chunk of the stage this thread gathers (wave-uniform)
+  const int u = tid / (NTHREADS / KS);  // chunk of the stage this thread gathers (wave-uniform: 256/KS threads per chunk)
   const int j = tid & 3;           // slot column
   const int rg = (tid >> 2) & (RST - 1);  // rows rg + RST i
 
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int EPI>
-static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
+template <typename T, int BN, int EPI, int KSV>
+static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
   const int mtiles = (a.M + BM - 1) / BM;
   const int ntiles = a.Npad / BN;
   dim3 grid(mtiles * ntiles), block(NTHREADS);
@@ -513,7 +513,7 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
   int nchunks = 0;
   for (int s = 0; s < a.nseg; ++s) nchunks += a.seg[s].nchunks;
-  const int smem = IgemmSmem<T, BN>::bytes(EPI) + kfl * 4 + nchunks * 16 + 16;
+  const int smem = IgemmSmem<T, BN, KSV>::bytes(EPI) + kfl * 4 + nchunks * 16 + 16;
   const Seg& s0 = a.seg[0];
   const bool lin = mfma && a.nseg == 1 && s0.ntaps == 1 && s0.taps[0] == 0 && s0.mode == G_PLAIN && s0.istride == 1 &&
                    s0.Hs == a.Ho && s0.Ws == a.Wo;
@@ -527,10 +527,10 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   constexpr int P1 = EPI == EPI_BNBWD ? 2 : 1;  // the prologue this epilogue normally sees
   void (*kern)(const ConvArgs);
   int ai;
-  if (!mfma) { kern = igemm_kernel<T, BN, EPI, false, false, -1>; ai = 0; }
-  else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1> : igemm_kernel<T, BN, EPI, true, false, P1>; ai = lin ? 1 : 2; }
-  else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0> : igemm_kernel<T, BN, EPI, true, false, 0>; ai = lin ? 3 : 4; }
-  else { kern = igemm_kernel<T, BN, EPI, true, false, -1>; ai = 5; }
+  if (!mfma) { kern = igemm_kernel<T, BN, EPI, false, false, -1, KSV>; ai = 0; }
+  else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1, KSV> : igemm_kernel<T, BN, EPI, true, false, P1, KSV>; ai = lin ? 1 : 2; }
+  else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0, KSV> : igemm_kernel<T, BN, EPI, true, false, 0, KSV>; ai = lin ? 3 : 4; }
+  else { kern = igemm_kernel<T, BN, EPI, true, false, -1, KSV>; ai = 5; }
   static int attr_bytes[6] = {0, 0, 0, 0, 0, 0};
   if (smem > 48 * 1024 && smem > attr_bytes[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -540,6 +540,14 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, grid, block, smem, st, a);
   return hipGetLastError();
+}
+
+// Chunks per stage: measured on MI355X (C2 b4) - 4 chunks per stage for the launches with <= 512 workgroups (halving their
+// stage chain at 128+ KB of LDS) made the step 1.2 ms slower, 1 chunk per stage for the 128-column variants (a third workgroup
+// per CU) was +-1 %; every variant therefore takes 2 chunks per stage.
+template <typename T, int BN, int EPI>
+static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
+  return launch_bn_ks<T, BN, EPI, ks_for(BN)>(a, mfma, st);
 }
 
 template <typename T, int EPI>
