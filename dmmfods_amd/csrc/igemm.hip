@@ -487,7 +487,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   }
 
   // ---- per-channel reductions: threads -> LDS -> one fp64 atomic per channel per workgroup ----
-  if (colvalid) {
+  // lanes l, l + NCV, l + 2 NCV, ... of a wave hold the same slot column: fold them with cross-lane adds first, so that one
+  // lane per column and wave touches LDS (4-way instead of 16..64-way contention on every fp64 LDS atomic)
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) {
+#pragma unroll
+    for (int d = NCV; d < 64; d <<= 1) {
+      s1[i] += __shfl_xor(s1[i], d, 64);
+      s2[i] += __shfl_xor(s2[i], d, 64);
+    }
+  }
+  if (colvalid && lane < NCV) {
 #pragma unroll
     for (int i = 0; i < SLOT; ++i) {
       atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
