@@ -28,6 +28,7 @@ template <> struct TT<f16> {
 };
 
 constexpr int MAX_TAPS = 52;
+constexpr int STAT_REPS = 8;   // replicas of the BatchNorm reduction accumulators (one per XCD)
 constexpr int BM = 128;        // rows (pixels) per workgroup tile
 constexpr int NTHREADS = 256;  // 4 waves of 64
 constexpr int ROWB = 64;       // LDS bytes per tile row = one K-chunk; the four 16-byte slots of a row are XOR-swizzled
@@ -82,6 +83,10 @@ struct ConvArgs {
   double* red1;    // sum dz
   double* red2;    // sum dz*xhat
   int accumulate;  // out += s*dz  instead of  out = s*dz
+  // The per-channel fp64 accumulators (stat_sum/stat_sq or red1/red2) exist in STAT_REPS replicas `stat_stride` doubles
+  // apart (0 = one copy): a workgroup adds into replica blockIdx % 8, i.e. the one its XCD owns, so the L2 atomics of the
+  // 8 XCDs never meet on a line and each address sees 1/8 of the traffic.  The finalize kernels add the replicas up.
+  int stat_stride;
   int pool2;       // each row is a 2x2-average-pooled pixel: distribute 0.25*acc to the 4 source pixels
 };
 

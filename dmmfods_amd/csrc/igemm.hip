@@ -505,11 +505,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
-  if (tid < BN && n0 + tid < a.N) {
+  if (!(IGEMM_DBG & 32) && tid < BN && n0 + tid < a.N) {
     double* d1 = (EPI == EPI_STORE) ? a.stat_sum : a.red1;
     double* d2 = (EPI == EPI_STORE) ? a.stat_sq : a.red2;
-    atomic_add_f64(d1 + n0 + tid, red[tid]);
-    atomic_add_f64(d2 + n0 + tid, red[BN + tid]);
+    const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+    atomic_add_f64(d1 + rep + n0 + tid, red[tid]);
+    atomic_add_f64(d2 + rep + n0 + tid, red[BN + tid]);
   }
 }
 

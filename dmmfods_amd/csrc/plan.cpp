@@ -266,6 +266,7 @@ struct Bn {
   float *gamma, *beta, *rm, *rv, *dgamma, *dbeta;
   float *scale, *shift, *mean, *invstd;
   double *red1, *red2;
+  int cp = 0;  // allocated channels = replica stride of red1 / red2
   std::vector<BnRange> ranges;
 };
 
@@ -346,7 +347,7 @@ struct Builder {
     const size_t n = (size_t)B * H * W_ * ld;
     b.x = wptr<uint8_t>(n * esz);
     if (grad) b.g = wptr<uint8_t>(n * esz);
-    if (stats) { b.ssum = zptr<double>(ld); b.ssq = zptr<double>(ld); }
+    if (stats) { b.ssum = zptr<double>((size_t)ld * STAT_REPS); b.ssq = zptr<double>((size_t)ld * STAT_REPS); }  // replica stride = ld
     if (grad) {
       b.q = zbptr<float>(ld + 8); b.r = zbptr<float>(ld + 8); b.ql = zbptr<float>(ld + 8); b.rl = zbptr<float>(ld + 8);
       b.qd = zbptr<double>(ld + 8); b.rd = zbptr<double>(ld + 8);
@@ -365,7 +366,8 @@ struct Builder {
     b.rm = P.buffers + rm.off; b.rv = P.buffers + rv.off;
     const int cp = rup(C, 8) + 8;
     b.scale = wptr<float>(cp); b.shift = wptr<float>(cp); b.mean = wptr<float>(cp); b.invstd = wptr<float>(cp);
-    b.red1 = zbptr<double>(cp); b.red2 = zbptr<double>(cp);
+    b.red1 = zbptr<double>((size_t)cp * STAT_REPS); b.red2 = zbptr<double>((size_t)cp * STAT_REPS);  // replica stride = cp
+    b.cp = cp;
     bns.push_back(b);
     return (int)bns.size() - 1;
   }
@@ -473,6 +475,7 @@ struct Builder {
       const Buf& sb = bufs[rg.buf];
       a.sum = sb.ssum ? sb.ssum + rg.ch0 : nullptr;
       a.sq = sb.ssq ? sb.ssq + rg.ch0 : nullptr;
+      a.stat_stride = sb.ld;
       a.count = rg.count;
       a.count_unbiased = rg.count_unb;
       a.gamma = b.gamma + rg.c0; a.beta = b.beta + rg.c0;
@@ -521,7 +524,7 @@ struct Builder {
       a.out = (void*)xat(c.obuf, c.och0);
       a.ldo = ob.ld; a.Hout = ob.H; a.Wout = ob.W;
       a.ostride = c.ostride; a.py = ph.py; a.px = ph.px;
-      if (c.stats && ob.ssum) { a.stat_sum = ob.ssum + c.och0; a.stat_sq = ob.ssq + c.och0; }
+      if (c.stats && ob.ssum) { a.stat_sum = ob.ssum + c.och0; a.stat_sq = ob.ssq + c.och0; a.stat_stride = ob.ld; }
       {
         char cb[32];
         const double np = (double)c.phases.size();
@@ -553,6 +556,7 @@ struct Builder {
       Op& o = push(OP_BNBWD);
       BnBwdFinalizeArgs& a = o.bb;
       a.red1 = b.red1 + rg.c0; a.red2 = b.red2 + rg.c0;
+      a.stat_stride = b.cp;
       a.mean = b.mean + rg.c0; a.invstd = b.invstd + rg.c0; a.scale = b.scale + rg.c0;
       a.dgamma = b.dgamma + rg.c0; a.dbeta = b.dbeta + rg.c0;
       const Buf& sb = bufs[rg.buf];
@@ -652,6 +656,7 @@ struct Builder {
       a.bscale = bn.scale + sr.bn_c0; a.bshift = bn.shift + sr.bn_c0;
       a.bmean = bn.mean + sr.bn_c0; a.binvstd = bn.invstd + sr.bn_c0;
       a.red1 = bn.red1 + sr.bn_c0; a.red2 = bn.red2 + sr.bn_c0;
+      a.stat_stride = bn.cp;
       a.accumulate = sb.ginit ? 1 : 0;
       a.pool2 = pool2;
       {

@@ -18,6 +18,7 @@ struct ConvertArgs {
 struct BnFinalizeArgs {
   const double* sum;
   const double* sq;
+  int stat_stride;  // doubles between the STAT_REPS replicas of sum / sq (0: a single copy)
   double count;           // positions the sums were taken over
   double count_unbiased;  // positions PyTorch's BatchNorm sees (differs for the nearest-upsampled head input)
   const float* gamma;
@@ -36,6 +37,7 @@ struct BnFinalizeArgs {
 struct BnBwdFinalizeArgs {
   const double* red1;  // sum dz
   const double* red2;  // sum dz*xhat
+  int stat_stride;     // doubles between the STAT_REPS replicas of red1 / red2 (0: a single copy)
   const float* mean;
   const float* invstd;
   const float* scale;

@@ -73,8 +73,11 @@ __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
   if (c >= a.C) return;
   float mean, var;
   if (a.training) {
-    const double m = a.sum[c] / a.count;
-    double v = a.sq[c] / a.count - m * m;
+    double su = a.sum[c], sq = a.sq[c];
+    if (a.stat_stride)
+      for (int k = 1; k < STAT_REPS; ++k) { su += a.sum[c + (size_t)k * a.stat_stride]; sq += a.sq[c + (size_t)k * a.stat_stride]; }
+    const double m = su / a.count;
+    double v = sq / a.count - m * m;
     if (v < 0) v = 0;
     mean = (float)m;
     var = (float)v;
@@ -101,7 +104,9 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
 __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.C) return;
-  const double S1 = a.red1[c], S2 = a.red2[c];
+  double S1 = a.red1[c], S2 = a.red2[c];
+  if (a.stat_stride)
+    for (int k = 1; k < STAT_REPS; ++k) { S1 += a.red1[c + (size_t)k * a.stat_stride]; S2 += a.red2[c + (size_t)k * a.stat_stride]; }
   const double mu = a.mean[c], is = a.invstd[c];
   const double dotp = S2;  // sum dz * xhat, reduced in centred form by the producing kernel
   a.dgamma[c] = (float)(dotp * a.grad_scale);
