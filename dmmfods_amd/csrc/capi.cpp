@@ -1,4 +1,5 @@
 // extern "C" surface of libdmmfods_hip.so (see include/dmmfods_hip.h) and the launch-list executor.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,8 +63,8 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
 void dmm_plan_destroy(dmm_plan* plan) {
   if (!plan) return;
   for (void* e : plan->fork_events) hipEventDestroy((hipEvent_t)e);
-  if (plan->join_event) hipEventDestroy((hipEvent_t)plan->join_event);
-  if (plan->side_stream) hipStreamDestroy((hipStream_t)plan->side_stream);
+  for (void* e : plan->join_events) hipEventDestroy((hipEvent_t)e);
+  for (void* s2 : plan->side_streams) hipStreamDestroy((hipStream_t)s2);
   delete plan;
 }
 
@@ -129,70 +130,68 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   // everything on one stream so that the event pairs bracket each kernel alone; a FILTERED profile (one kernel class) runs
   // as in production.
   const bool overlap = g_overlap_wgrad && (evs == nullptr || !filt.empty());
-  hipStream_t side = nullptr;
+  constexpr int nside = 1;  // 2 and 3 side streams measured: 0.3 / 0.6 ms slower; and the leaf chains need one FIFO
   size_t nfork = 0;
   bool forked = false;
   if (overlap) {
-    if (!p->side_stream) {
+    while ((int)p->side_streams.size() < nside) {
       int lo = 0, hi = 0;
       hipDeviceGetStreamPriorityRange(&lo, &hi);
       hipStream_t s2;
       if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
       hipEvent_t je;
       if (hipEventCreateWithFlags(&je, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
-      p->side_stream = (void*)s2;
-      p->join_event = (void*)je;
+      p->side_streams.push_back((void*)s2);
+      p->join_events.push_back((void*)je);
     }
-    side = (hipStream_t)p->side_stream;
   }
   auto join = [&]() {
     if (forked) {
-      hipEventRecord((hipEvent_t)p->join_event, side);
-      hipStreamWaitEvent(st, (hipEvent_t)p->join_event, 0);
+      for (int k = 0; k < nside; ++k) {
+        hipEventRecord((hipEvent_t)p->join_events[k], (hipStream_t)p->side_streams[k]);
+        hipStreamWaitEvent(st, (hipEvent_t)p->join_events[k], 0);
+      }
       forked = false;
     }
   };
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& o = ops[i];
     hipError_t e = hipSuccess;
-    if (overlap && o.kind == OP_WGRAD) {
+    // side-stream launches: weight gradients and the leaves of the backward graph (stem, raw-input branches)
+    hipStream_t lst = st;
+    if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
       if (nfork >= p->fork_events.size()) {
         hipEvent_t fe;
         if (hipEventCreateWithFlags(&fe, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
         p->fork_events.push_back((void*)fe);
       }
+      lst = (hipStream_t)p->side_streams[0];
       hipEvent_t fe = (hipEvent_t)p->fork_events[nfork++];
       hipEventRecord(fe, st);
-      hipStreamWaitEvent(side, fe, 0);
-      const bool sel = selected(o);
-      if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], side);
-      e = launch_wgrad(o.w, dt, mfma, side);
-      if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], side);
+      hipStreamWaitEvent(lst, fe, 0);
       forked = true;
-      if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " (wgrad, side stream): " + hipGetErrorString(e));
-      continue;
     }
     if (o.kind == OP_UNPACK) join();
     const bool sel = selected(o);
-    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], st);
+    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], lst);
     switch (o.kind) {
-      case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, st); break;
-      case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, st); break;
-      case OP_CONVERT: e = launch_convert_input(o.cv, dt, st); break;
-      case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, st); break;
-      case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, st); break;
-      case OP_BNFIN: e = launch_bn_finalize(o.bf, st); break;
-      case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, st); break;
-      case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, st); break;
-      case OP_POOLBWD: e = launch_maxpool_bwd(o.mpb, dt, st); break;
-      case OP_BCE: e = launch_bce_metrics(o.bce, dt, st); break;
-      case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, st); break;
-      case OP_APPLYCORR: e = launch_apply_corr(o.ac, dt, st); break;
-      case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, st); break;
+      case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, lst); break;
+      case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, lst); break;
+      case OP_CONVERT: e = launch_convert_input(o.cv, dt, lst); break;
+      case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst); break;
+      case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst); break;
+      case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
+      case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
+      case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, lst); break;
+      case OP_POOLBWD: e = launch_maxpool_bwd(o.mpb, dt, lst); break;
+      case OP_BCE: e = launch_bce_metrics(o.bce, dt, lst); break;
+      case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, lst); break;
+      case OP_APPLYCORR: e = launch_apply_corr(o.ac, dt, lst); break;
+      case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, lst); break;
       default: return fail(DMM_ERR_STATE, "unknown op");
     }
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
-    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], st);
+    if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], lst);
   }
   join();
   return DMM_OK;

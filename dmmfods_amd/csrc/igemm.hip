@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
       for (int e = 0; e < SLOT; ++e) { xpre[i][e] = (T)0; gpre[i][e] = (T)0; }
       if (ppre[i] >= 0) {
         xpre[i] = *(const V*)(bx + (size_t)pix * a.ldbx + n);
-        if (a.accumulate) gpre[i] = *(const V*)(g + (size_t)pix * a.ldo + n);
+        if (a.accumulate && g != nullptr) gpre[i] = *(const V*)(g + (size_t)pix * a.ldo + n);
       }
     }
   }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
           s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
           gf[e] += sc[e] * dz;
         }
-        *(V*)(g + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
+        if (g != nullptr) *(V*)(g + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);  // null: only the reductions are wanted
       }
     }
     const int nsub = a.pool2 ? 4 : 1;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
         const size_t p = (size_t)pix + (sub >> 1) * a.Wout + (sub & 1);
         float xf[SLOT], gf[SLOT];
         vec_to_f32<T>(*(const V*)(bx + p * a.ldbx + n), xf);
-        if (a.accumulate) vec_to_f32<T>(*(const V*)(g + p * a.ldo + n), gf);
+        if (a.accumulate && g != nullptr) vec_to_f32<T>(*(const V*)(g + p * a.ldo + n), gf);
 #pragma unroll
         for (int i = 0; i < SLOT; ++i) {
           const float dz = (fmaf(xf[i], sc[i], sh[i]) > 0.f) ? av[i] * wgt : 0.f;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
           s2[i] = fmaf(dz, (xf[i] - mu[i]) * is[i], s2[i]);  // sum dz * xhat: centred, so nothing cancels later
           gf[i] = (a.accumulate ? gf[i] : 0.f) + sc[i] * dz;
         }
-        *(V*)(g + p * a.ldo + n) = f32_to_vec<T>(gf);
+        if (g != nullptr) *(V*)(g + p * a.ldo + n) = f32_to_vec<T>(gf);
       }
     }
   }

@@ -421,11 +421,14 @@ struct Builder {
   }
 
   // -------------------------------------------------------------------------------- op emission
+  bool leaf_scope = false;  // ops emitted now feed only parameter gradients (stem / raw-input branches)
   Op& push(int kind) {
     ops->emplace_back();
     ops->back().kind = kind;
+    ops->back().leaf = leaf_scope ? 1 : 0;
     return ops->back();
   }
+  bool is_raw_input(int buf) const { return buf == in1 || buf == in2 || buf == inH; }
   void tag(Op& o, const char* cls, const std::string& layer, double flops, double bytes) {
     snprintf(o.label, sizeof(o.label), "%s/%s", cls, layer.c_str());
     o.flops = flops;
@@ -553,7 +556,10 @@ struct Builder {
   void emit_bn_bwd_finalize(int bn) {
     Bn& b = bns[bn];
     for (auto& rg : b.ranges) {
+      const bool outer = leaf_scope;
+      leaf_scope = outer || is_raw_input(rg.buf);
       Op& o = push(OP_BNBWD);
+      leaf_scope = outer;
       BnBwdFinalizeArgs& a = o.bb;
       a.red1 = b.red1 + rg.c0; a.red2 = b.red2 + rg.c0;
       a.stat_stride = b.cp;
@@ -638,7 +644,12 @@ struct Builder {
         case DG_CONVT: taps = taps_convT_dgrad(); istride = 2; break;
         case DG_UP2: taps = taps_up2_merged_dgrad(); istride = 2; break;
       }
+      // the gradient w.r.t. a raw input is only needed for the BatchNorm parameter gradients of the norm in front of the
+      // conv: its launch reduces sum(dz), sum(dz*xhat), stores nothing, and is a leaf of the backward graph
+      const bool raw = is_raw_input(sr.buf);
+      leaf_scope = raw;
       Op& o = push(OP_IGEMM);
+      leaf_scope = false;
       o.epi = EPI_BNBWD;
       ConvArgs& a = o.c;
       memset(&a, 0, sizeof(a));
@@ -648,7 +659,7 @@ struct Builder {
       const PackDesc& pd = P.packs[c.dpack[s]];
       a.wpack = pd.dst;
       a.N = sr.C; a.Npad = pd.Npad;
-      a.out = gat(sr.buf, sr.ch0);
+      a.out = raw ? nullptr : gat(sr.buf, sr.ch0);
       a.ldo = sb.ld; a.Hout = sb.H; a.Wout = sb.W; a.ostride = ostride; a.py = 0; a.px = 0;
       a.bx = xat(sr.buf, sr.ch0);
       a.ldbx = sb.ld;
@@ -657,7 +668,7 @@ struct Builder {
       a.bmean = bn.mean + sr.bn_c0; a.binvstd = bn.invstd + sr.bn_c0;
       a.red1 = bn.red1 + sr.bn_c0; a.red2 = bn.red2 + sr.bn_c0;
       a.stat_stride = bn.cp;
-      a.accumulate = sb.ginit ? 1 : 0;
+      a.accumulate = (sb.ginit && !raw) ? 1 : 0;
       a.pool2 = pool2;
       {
         char cb[32];
@@ -667,7 +678,7 @@ struct Builder {
         tag(o, ncls("igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
-      sb.ginit = true;
+      if (!raw) sb.ginit = true;
     }
     int done = -1;
     for (int s = 0; s < c.nseg; ++s) {
@@ -691,6 +702,8 @@ struct Builder {
     tag(o, "maxpool.fwd", "pool0", 0, ((double)yb.B * yb.H * yb.W + (double)ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
   }
   void emit_pool_bwd(PoolRec& p) {
+    // the stem: pool0 backward, norm0's reductions and conv0's weight gradient feed parameter gradients only
+    leaf_scope = true;
     Op& o = push(OP_POOLBWD);
     MaxpoolBwdArgs& a = o.mpb;
     Buf &yb = bufs[p.y0buf];
@@ -707,6 +720,7 @@ struct Builder {
     tag(o, "maxpool.bwd", "pool0", 0, (2.0 * yb.B * yb.H * yb.W + 2.0 * ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
     yb.ginit = true;
     emit_bn_bwd_finalize(p.bn);
+    leaf_scope = false;
   }
 
   // -------------------------------------------------------------------------------- layer records

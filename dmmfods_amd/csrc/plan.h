@@ -42,6 +42,7 @@ struct PackArgs { const PackDesc* descs; const int* prefix; int ndesc, total_row
 struct Op {
   int kind;
   int epi;
+  int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it)
   double flops;    // algorithmic 2*MACs of this launch (reference formulation)
   double bytes;    // algorithmic HBM bytes: every operand read once, every result written once
   char label[56];  // kernel class / layer
@@ -59,7 +60,7 @@ struct Op {
     PackArgs pk;
     ApplyCorrArgs ac;
   };
-  Op() : kind(0), epi(0), flops(0), bytes(0) { label[0] = 0; }
+  Op() : kind(0), epi(0), leaf(0), flops(0), bytes(0) { label[0] = 0; }
 };
 
 }  // namespace dmm
@@ -90,7 +91,6 @@ struct dmm_plan {
   std::vector<std::vector<void*>> prof_events[2];  // [which][pass] -> one (start, end) event pair per op
   std::string prof_filter;                         // only ops whose label starts with this are bracketed (empty: all)
   // weight-gradient GEMMs run on a second stream beside the data-gradient chain (nothing reads them before unpack)
-  void* side_stream = nullptr;
+  std::vector<void*> side_streams, join_events;  // weight gradients are dealt round-robin to these
   std::vector<void*> fork_events;
-  void* join_event = nullptr;
 };
