@@ -303,6 +303,83 @@ def g4_c1(M, H):
     print("G4 ->", os.path.getsize(path) // 1024, "KiB")
 
 
+# ------------------------------------------------------------------ G3 layer-level vectors
+G3_ARCH = dict(growth_rate=24, block_config=(2, 2, 2, 2), num_init_features=48)  # K = 48, 72, 96: not powers of two, not x32
+G3_MODULES = ["features.relu0", "features.pool0", "features.denseblock1", "features.denseblock1.denselayer2",
+              "features.transition1", "features.denseblock3", "features.transition3", "features.denseblock4", "concat_module",
+              "decoder.Transposed_Convolution_Sequence_1", "decoder.Transposed_Convolution_1",
+              "decoder.Transposed_Convolution_Sequence_3", "decoder.Transposed_Convolution_3", "decoder.Transposed_Convolution_4",
+              "dec_out_to_heat_maps.refine0", "dec_out_to_heat_maps"]
+
+
+def g3_layers(M, H):
+    """Forward-hook outputs of individual reference modules (one dense layer, dense blocks, transitions, fusion module, decoder
+    stages incl. the ConvTranspose output_size path, head) and the gradients of their weights, at channel counts that are
+    neither powers of two nor multiples of 32."""
+    for vname in ("early", "mid3"):
+        arch = variant_arch(G3_ARCH, vname)
+        model = M.Dense_U_Net_lidar(ref_config(H, arch))
+        model.load_state_dict(R.make_state(arch, seed=321), strict=True)
+        model.train()
+        outs = {}
+        mods = dict(model.named_modules())
+        for name in G3_MODULES:
+            if name in mods:
+                mods[name].register_forward_hook(lambda m, i, o, name=name: outs.__setitem__(name, o.detach()))
+        rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=7)
+        pred = model(rgb, lidar)
+        cur = torch.nn.BCEWithLogitsLoss(reduction="none")(pred, tgt)
+        cur.backward(torch.ones_like(cur.detach()))
+        store = {"logits_full": pred.detach().numpy().copy()}
+        for name, t in outs.items():
+            put(store, f"out/{name}", digest(t, nsample=4096))
+        for k, p_ in model.named_parameters():
+            put(store, f"grad/{k}", digest(p_.grad, nsample=256))
+        store["meta/arch"] = np.frombuffer(json.dumps(dict(G3_ARCH, variant=vname, B=2, H=64, W=96, weight_seed=321,
+                                                          data_seed=7)).encode(), dtype=np.uint8)
+        path = os.path.join(GOLD, f"g3_layers_{vname}.npz")
+        np.savez_compressed(path, **store)
+        print("G3", vname, "->", os.path.getsize(path) // 1024, "KiB", sorted(outs))
+
+
+# ------------------------------------------------------------------ G5 shape / FLOP trace
+G5_CONFIGS = {  # BASELINE.json configs (SURVEY 8): densenet, variant, batch, H, W
+    "c1": (121, "no", 1, 256, 384), "c2": (121, "early", 4, 1280, 1920), "c3": (121, "mid3", 4, 1280, 1920),
+    "c4": (169, "mid3", 2, 1280, 1920), "c5": (201, "mid3", 8, 640, 960),
+}
+
+
+def g5_trace(M, H):
+    """Per-convolution shapes and forward FLOPs (2 MACs) of the reference module, traced on the meta device (no arithmetic)."""
+    out = {}
+    for cname, (dn, vname, B, Hh, Ww) in G5_CONFIGS.items():
+        arch = variant_arch(R.DENSENETS[dn], vname)
+        with torch.device("meta"):
+            model = M.Dense_U_Net_lidar(ref_config(H, arch))
+        rows = []
+
+        def hook(m, i, o, name=None):
+            x = i[0]
+            if isinstance(m, nn.ConvTranspose2d):
+                fl = 2.0 * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] * x.shape[2] * x.shape[3]
+            else:
+                fl = 2.0 * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1] * o.shape[2] * o.shape[3]
+            rows.append([name, type(m).__name__, m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0],
+                         int(o.shape[2]), int(o.shape[3]), fl])
+
+        for name, m in model.named_modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.register_forward_hook(lambda m, i, o, name=name: hook(m, i, o, name))
+        s1 = torch.empty(1, arch.stream_1_in_channels, Hh, Ww, device="meta")
+        s2 = torch.empty(1, max(arch.stream_2_in_channels, 1), Hh, Ww, device="meta")
+        model(s1, s2)
+        out[cname] = dict(densenet=dn, variant=vname, batch=B, H=Hh, W=Ww, num_params=int(model.num_params),
+                          fwd_gflop_per_img=sum(r[-1] for r in rows) / 1e9, convs=rows)
+        print("G5", cname, round(out[cname]["fwd_gflop_per_img"], 2), "GFLOP/img,", len(rows), "convs")
+    with gzip.open(os.path.join(GOLD, "g5_flop_trace.json.gz"), "wt") as f:
+        json.dump(out, f)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -311,6 +388,8 @@ def main():
     g1_topology(M, H)
     g2_tiny(M, H)
     g4_c1(M, H)
+    g3_layers(M, H)
+    g5_trace(M, H)
     leaked = [p for p, _, fs in os.walk(REF) if os.path.basename(p) == "__pycache__"]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

@@ -296,14 +296,23 @@ def _stem(ctx: _Ctx, x: torch.Tensor, prefix: str):
 
 
 def forward(P: Dict[str, torch.Tensor], arch: Arch, stream_1: torch.Tensor, stream_2: Optional[torch.Tensor],
-            training: bool = True, storage=None) -> torch.Tensor:
+            training: bool = True, storage=None, capture: Optional[dict] = None) -> torch.Tensor:
     """Logits (B, num_classes, H, W).  BN running stats / num_batches_tracked in ``P`` are updated in
     place when ``training`` (as nn.BatchNorm2d does).  Mirrors M:210-267.
 
     ``storage`` (e.g. torch.float16) rounds inputs, packed weights and every tensor the HIP path stores
     (conv / pool / transposed-conv outputs) to that dtype with straight-through gradients; the arithmetic stays
-    in the tensors' own dtype.  It is the yardstick for the fp16 build: what fp16 storage alone does to the result."""
+    in the tensors' own dtype.  It is the yardstick for the fp16 build: what fp16 storage alone does to the result.
+
+    ``capture`` (a dict) receives the outputs at the reference's module boundaries, keyed by the reference module name
+    (``features.denseblock2``, ``features.transition1``, ``decoder.Transposed_Convolution_3``, ...): the layer-level golden
+    vectors (tests/golden/g3_layers_*.npz) are forward-hook outputs of exactly those modules."""
     ctx = _Ctx(P, training, storage)
+
+    def cap(name, t):
+        if capture is not None:
+            capture[name] = t
+        return t
     stream_1 = ctx.st(stream_1)
     if stream_2 is not None:
         stream_2 = ctx.st(stream_2)
@@ -328,29 +337,32 @@ def forward(P: Dict[str, torch.Tensor], arch: Arch, stream_1: torch.Tensor, stre
 
     skips, sizes = [raw], []
     y0, x = _stem(ctx, x, "features")
+    cap("features.relu0", y0)
+    cap("features.pool0", x)
     sizes.append(y0.shape[2:])
     for bi in range(nb):
         if fusion == "mid" and bi == arch.concat_before_block_num - 1:  # after transition_{cbb-1} (M:242-245)
             assert x.shape == s2_feat.shape, f"{tuple(x.shape)} {tuple(s2_feat.shape)}"
-            x = ctx.conv(ctx.bn_relu(torch.cat((x, s2_feat), 1), "concat_module.norm"), "concat_module.conv")
-        x = _dense_block(ctx, x, f"features.denseblock{bi + 1}", arch.block_config[bi])
+            x = cap("concat_module", ctx.conv(ctx.bn_relu(torch.cat((x, s2_feat), 1), "concat_module.norm"), "concat_module.conv"))
+        x = cap(f"features.denseblock{bi + 1}", _dense_block(ctx, x, f"features.denseblock{bi + 1}", arch.block_config[bi]))
         if bi != nb - 1:
             skips.append(x)
             sizes.append(x.shape[2:])
-            x = _transition(ctx, x, f"features.transition{bi + 1}")
+            x = cap(f"features.transition{bi + 1}", _transition(ctx, x, f"features.transition{bi + 1}"))
 
     for j in range(1, nb + 1):  # decoder (M:255-261)
         if j > 1:
             x = torch.cat((x, skips.pop()), 1)
         p = f"decoder.Transposed_Convolution_Sequence_{j}"
-        x = ctx.bn_relu(ctx.conv(ctx.bn_relu(x, p + ".norm0"), p + ".conv_reduce"), p + ".norm1")
+        x = cap(p, ctx.bn_relu(ctx.conv(ctx.bn_relu(x, p + ".norm0"), p + ".conv_reduce"), p + ".norm1"))
         hw = sizes.pop()
         x = ctx.st(F.conv_transpose2d(x, ctx.st(P[f"decoder.Transposed_Convolution_{j}.weight"]), None, stride=2,
                                       padding=1, output_padding=1))
         assert tuple(x.shape[2:]) == tuple(hw)
+        cap(f"decoder.Transposed_Convolution_{j}", x)
     x = F.interpolate(x, scale_factor=2, mode="nearest")
     x = torch.cat((x, skips.pop()), 1)  # raw input again (M:264)
-    x = ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm0"), "dec_out_to_heat_maps.refine0", padding=1)
+    x = cap("dec_out_to_heat_maps.refine0", ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm0"), "dec_out_to_heat_maps.refine0", padding=1))
     x = ctx.conv(ctx.bn_relu(x, "dec_out_to_heat_maps.norm1"), "dec_out_to_heat_maps.refine1", padding=2, store=False)
     return x
 

@@ -38,8 +38,8 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def _oracle_step(R, arch, dt, B=2, H=64, W=96, seed=0, storage=None, update=False):
-    P = {k: (t.to(dt) if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=123).items()}
+def _oracle_step(R, arch, dt, B=2, H=64, W=96, seed=0, storage=None, update=False, wseed=123):
+    P = {k: (t.to(dt) if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=wseed).items()}
     tr = R.Trainer(arch, P, storage=storage)
     rgb, lidar, tgt = R.make_inputs(arch, B, H, W, seed=seed)
     out = tr.step(rgb.to(dt), lidar.to(dt), tgt.to(dt), do_update=update)
@@ -79,6 +79,37 @@ def test_tiny_training_step_fp32(variant, golden_dir):
             assert _rel(v, P64[k]) < 1e-4, k
         if k.endswith("num_batches_tracked"):
             assert int(v) == 1
+
+
+G3_ARCH = dict(growth_rate=24, block_config=(2, 2, 2, 2), num_init_features=48)
+
+
+@pytest.mark.parametrize("variant", ["early", "mid3"])
+def test_odd_channel_counts_against_reference_vectors_fp32(variant, golden_dir):
+    """K = 48 / 72 / 96 channels (chunk tails in every gather): logits and every parameter gradient against the fixture
+    recorded from the reference module (tests/golden/g3_layers_*.npz)."""
+    from oracle import restatement as R
+    from tests.test_oracle_golden import _check_digest
+    arch = _arch(R, G3_ARCH, variant)
+    g = np.load(os.path.join(golden_dir, f"g3_layers_{variant}.npz"))
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=321))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=7)
+    logits = model(rgb.to(DEV), lidar.to(DEV))
+    model.loss_backward(tgt.to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(logits.detach(), torch.from_numpy(g["logits_full"])) < 1e-3
+    # gradients: against the reference's vectors (fp32 CPU, its own summation noise) and, noise-aware, against the fp64 oracle
+    o64, g64, _, _ = _oracle_step(R, arch, torch.float64, seed=7, wseed=321)
+    o32, g32, _, _ = _oracle_step(R, arch, torch.float32, seed=7, wseed=321)
+    for k, p in model.named_parameters():
+        _check_digest(g, f"grad/{k}", p.grad.detach().cpu(), rtol=1e-2)
+        ref = g64[k]
+        s = ref.abs().max().clamp_min(1e-30)
+        err = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
+        noise = ((g32[k].double() - ref).abs().max() / s).item()
+        assert err < max(3e-3, 4 * noise), (k, err, noise)
 
 
 @pytest.mark.parametrize("variant", ["no", "mid3"])

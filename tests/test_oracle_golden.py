@@ -154,3 +154,56 @@ def test_size_constraint_raises_like_reference():
     P = R.make_state(arch)
     with pytest.raises(ValueError):
         R.forward(P, arch, torch.zeros(1, 3, 100, 100), None)
+
+
+G3_ARCH = dict(growth_rate=24, block_config=(2, 2, 2, 2), num_init_features=48)
+
+
+@pytest.mark.parametrize("variant", ["early", "mid3"])
+def test_g3_layer_level_vectors(golden_dir, variant):
+    """Forward-hook outputs of individual reference modules (dense layer / blocks, transitions, fusion module, decoder stages,
+    ConvTranspose with output_size, head) and every parameter gradient, at K = 48 / 72 / 96 channels."""
+    g = np.load(os.path.join(golden_dir, f"g3_layers_{variant}.npz"))
+    arch = _arch(G3_ARCH, variant)
+    P = R.make_state(arch, seed=321)
+    for t in P.values():
+        if t.is_floating_point():
+            t.requires_grad_(False)
+    leaves = R.leaf_params(P, arch)
+    for _, t in leaves:
+        t.requires_grad_(True)
+    rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=7)
+    cap = {}
+    logits = R.forward(P, arch, rgb, lidar if arch.fusion != "no" else None, training=True, capture=cap)
+    R.bce_with_logits(logits, tgt).sum().backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits_full"], rtol=1e-4, atol=1e-4 * np.abs(g["logits_full"]).max())
+    names = sorted({k.split("/")[1] for k in g.files if k.startswith("out/")})
+    assert len(names) >= 15
+    checked = 0
+    for name in names:
+        if name == "dec_out_to_heat_maps":          # the head module's output is the logits tensor
+            _check_digest(g, f"out/{name}", logits, rtol=1e-4)
+        elif name == "features.denseblock1.denselayer2":
+            # a dense layer returns only its new growth channels: the last 24 channels of the block output
+            _check_digest(g, f"out/{name}", cap["features.denseblock1"][:, -arch.growth_rate:], rtol=1e-4)
+        else:
+            assert name in cap, name
+            _check_digest(g, f"out/{name}", cap[name], rtol=1e-4)
+        checked += 1
+    assert checked == len(names)
+    for k, t in leaves:
+        _check_digest(g, f"grad/{k}", t.grad, rtol=2e-3)  # BN-parameter gradients are cancelling sums: fp32 order noise
+
+
+def test_g5_flop_trace_matches_restatement(golden_dir):
+    """Per-config forward FLOPs and parameter counts traced on the reference module (meta device) = what the oracle counts."""
+    with gzip.open(os.path.join(golden_dir, "g5_flop_trace.json.gz"), "rt") as f:
+        g5 = json.load(f)
+    want = {"c1": 36.75, "c2": 938.7, "c3": 1133.1, "c4": 1220.2, "c5": 348.9}   # SURVEY 8
+    for cname, ent in g5.items():
+        arch = _arch(R.DENSENETS[ent["densenet"]], ent["variant"])
+        assert R.num_params(arch) == ent["num_params"], cname
+        fl = R.conv_flops_forward(arch, ent["H"], ent["W"]) / 1e9
+        assert abs(fl - ent["fwd_gflop_per_img"]) < 1e-6 * ent["fwd_gflop_per_img"] + 1e-6, (cname, fl, ent["fwd_gflop_per_img"])
+        assert abs(ent["fwd_gflop_per_img"] - want[cname]) < 0.06, cname
+        assert len(ent["convs"]) == sum(1 for _, _, kind in R.param_table(arch) if kind in ("conv", "convT")), cname
