@@ -415,9 +415,9 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.rows_per_split <= 0) {
     const int wbn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
     const int base = a.kgroups * (a.Npad / wbn);
-    // ~512 workgroups for short row ranges (every workgroup ends with WBN x 128 atomics); long ranges are cut finer, down
+    // ~256 workgroups for short row ranges (fewer, longer workgroups also leave the other stream more room) (every workgroup ends with WBN x 128 atomics); long ranges are cut finer, down
     // to 32 row steps per workgroup, which evens out the tail of the launch
-    static const int target = getenv("DMM_WGRAD_WGS") ? atoi(getenv("DMM_WGRAD_WGS")) : 512;
+    static const int target = getenv("DMM_WGRAD_WGS") ? atoi(getenv("DMM_WGRAD_WGS")) : 256;
     const int steps = (a.M + bmw - 1) / bmw;
     const int want = (target + base - 1) / base, want_hi = (8 * target + base - 1) / base;
     int per = (steps + want - 1) / want;
