@@ -327,3 +327,35 @@ def test_thin_logits_kernel_matches_generic_kernels():
         assert float((out[1] - out[0]).abs().max()) <= 1e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
     with pytest.raises(ValueError):
         _lib.check(_lib.lib().dmm_set_option(b"no_such_option", 1))
+
+
+@pytest.mark.gpu
+def test_two_stream_backward_matches_single_stream():
+    """Weight gradients and backward leaves on the side stream (Streams) against the same launches on one stream:
+    the only difference allowed is the order of fp32 atomic adds."""
+    from oracle import restatement as R
+    from dmmfods_amd import _lib
+    arch = _arch(R, dict(growth_rate=16, block_config=(2, 3, 2, 2), num_init_features=32), "mid3")
+    model = _model(arch, dtype="fp16")
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, 2, 128, 192, seed=3)
+    rgb, lidar, tgt = rgb.to(DEV), lidar.to(DEV), tgt.to(DEV)
+    L = _lib.lib()
+    out = {}
+    try:
+        for rep in range(6):
+            on = rep % 2
+            _lib.check(L.dmm_set_option(b"overlap_wgrad", on))
+            with torch.no_grad():
+                model(rgb, lidar)
+            model.loss_backward(tgt)
+            torch.cuda.synchronize()
+            g = model.grad_arena.double().clone()
+            assert torch.isfinite(g).all()
+            if 0 in out:
+                assert ((g - out[0]).norm() / out[0].norm()).item() < 1e-5, (rep, on)
+            else:
+                out[0] = g
+    finally:
+        _lib.check(L.dmm_set_option(b"overlap_wgrad", 1))
