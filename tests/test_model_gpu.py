@@ -335,7 +335,7 @@ def test_two_stream_backward_matches_single_stream():
     the only difference allowed is the order of fp32 atomic adds."""
     from oracle import restatement as R
     from dmmfods_amd import _lib
-    arch = _arch(R, dict(growth_rate=16, block_config=(2, 3, 2, 2), num_init_features=32), "mid3")
+    arch = _arch(R, dict(growth_rate=16, block_config=(2, 2, 2, 2), num_init_features=32), "mid3")
     model = _model(arch, dtype="fp16")
     model.load_state_dict(R.make_state(arch, seed=11))
     model = model.to(DEV).train()
