@@ -193,7 +193,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("DMM_FORCE_DIST"))  # the second form exercises the N>1 code path on one GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
