@@ -192,12 +192,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
       *(V*)(out + (size_t)p * a.ldo + c) = ov;
       float r[SLOT];
       vec_to_f32<T>(ov, r);
+      unsigned long long packed = 0;  // the slot's argmax bytes leave in one store
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
-        a.argmax[(size_t)p * a.C + c + i] = (unsigned char)arg[i];
+        packed |= (unsigned long long)(unsigned)arg[i] << (8 * i);
         s1[i] += (double)r[i];
         s2[i] += (double)r[i] * (double)r[i];
       }
+      if constexpr (SLOT == 8) *(unsigned long long*)(a.argmax + (size_t)p * a.C + c) = packed;
+      else *(unsigned*)(a.argmax + (size_t)p * a.C + c) = (unsigned)packed;
     }
   }
   block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.stat_sum, a.stat_sq);
@@ -266,9 +269,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
           float gf[SLOT], xf[SLOT];
           vec_to_f32<T>(*(const V*)(gp + op * a.ldg + c), gf);
           vec_to_f32<T>(*(const V*)(xp + op * a.ldg + c), xf);
+          unsigned long long am;  // the slot's argmax bytes in one load
+          if constexpr (SLOT == 8) am = *(const unsigned long long*)(a.argmax + op * a.C + c);
+          else am = *(const unsigned*)(a.argmax + op * a.C + c);
 #pragma unroll
           for (int i = 0; i < SLOT; ++i)
-            if (a.argmax[op * a.C + c + i] == k) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
+            if ((int)((am >> (8 * i)) & 0xff) == k) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
         }
       }
       float yf[SLOT], o[SLOT];
