@@ -177,15 +177,25 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
       int arg[SLOT];
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) { best[i] = -INFINITY; arg[i] = 0; }
+      // all nine window loads are issued before the first compare (out-of-image taps re-read the centre pixel and are
+      // skipped by the predicate), so one memory latency is paid per output instead of nine
+      V win[9];
+      bool ok[9];
+#pragma unroll
       for (int k = 0; k < 9; ++k) {
         const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
-        if (iy < 0 || ix < 0 || iy >= a.H0 || ix >= a.W0) continue;
+        ok[k] = iy >= 0 && ix >= 0 && iy < a.H0 && ix < a.W0;
+        const int cy = ok[k] ? iy : 2 * oy, cx = ok[k] ? ix : 2 * ox;
+        win[k] = *(const V*)(y0 + ((size_t)(b * a.H0 + cy) * a.W0 + cx) * a.ld0 + c);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
         float f[SLOT];
-        vec_to_f32<T>(*(const V*)(y0 + ((size_t)(b * a.H0 + iy) * a.W0 + ix) * a.ld0 + c), f);
+        vec_to_f32<T>(win[k], f);
 #pragma unroll
         for (int i = 0; i < SLOT; ++i) {
           const float v = fmaxf(fmaf(f[i], sc[i], sh[i]), 0.f);
-          if (v > best[i]) { best[i] = v; arg[i] = k; }
+          if (ok[k] && v > best[i]) { best[i] = v; arg[i] = k; }
         }
       }
       const V ov = f32_to_vec<T>(best);
