@@ -147,7 +147,7 @@ def roofline_block(classes, dtype, workload=None, timed=None):
     return roof, table
 
 
-def cpu_baseline(max_seconds=25.0):
+def cpu_baseline(min_seconds=10.0, max_steps=60):
     """The CPU oracle (oracle/restatement.py, kind 'port') timed on this host: BASELINE.json configs[0] (C1)."""
     from oracle import restatement as R
     try:
@@ -166,13 +166,15 @@ def cpu_baseline(max_seconds=25.0):
     tr.step(rgb, lidar, tgt)  # warm-up
     print(f"[bench] cpu_baseline: warm-up step {time.time() - t_start:.2f} s", file=sys.stderr, flush=True)
     times = []
-    while len(times) < 5 and (not times or time.time() - t_start < max_seconds):
+    t_timed = time.time()
+    while len(times) < max_steps and (len(times) < 5 or time.time() - t_timed < min_seconds):  # a bounded ~10 s sample
         t0 = time.time()
         tr.step(rgb, lidar, tgt)
         times.append(time.time() - t0)
     best = min(times)
+    median = sorted(times)[len(times) // 2]
     return dict(value=round(1.0 / best, 4), unit="img/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"C1 d121 no-fusion 1x3x256x384 fp32 fwd+BCE+bwd+Adam, {len(times)} steps after 1 warm-up, best {best:.3f} s/step "
+                sample=f"C1 d121 no-fusion 1x3x256x384 fp32 fwd+BCE+bwd+Adam, {len(times)} steps ({sum(times):.1f} s) after 1 warm-up, best {best:.3f} / median {median:.3f} s/step "
                        f"(= {109.8 / best:.1f} conv GFLOP/s); the GPU workload is 25.4x more conv FLOPs per image")
 
 
