@@ -359,3 +359,31 @@ def test_two_stream_backward_matches_single_stream():
                 out[0] = g
     finally:
         _lib.check(L.dmm_set_option(b"overlap_wgrad", 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,variant", [(169, "mid3"), (201, "early"), (161, "mid2")])
+def test_other_densenet_depths_forward_backward_fp32(depth, variant):
+    """The C4 / C5 architectures (DenseNet-169 / -201; -161 has growth 48 and 96 stem channels) at a small image size: logits and
+    all gradients against the fp64 oracle, noise-aware like the other gradient checks."""
+    from oracle import restatement as R
+    arch = _arch(R, R.DENSENETS[depth], variant)
+    o64, g64, _, _ = _oracle_step(R, arch, torch.float64, B=1, H=64, W=96, seed=5, wseed=77)
+    o32, g32, _, _ = _oracle_step(R, arch, torch.float32, B=1, H=64, W=96, seed=5, wseed=77)
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=77))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, 1, 64, 96, seed=5)
+    logits = model(rgb.to(DEV), lidar.to(DEV))
+    met = model.loss_backward(tgt.to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(logits.detach(), o64["logits"]) < 1e-3
+    assert _rel(met["loss_per_class"], o64["loss_per_class"]) < 1e-4
+    num = den = num32 = 0.0
+    for k, p in model.named_parameters():
+        ref = g64[k]
+        num += float((p.grad.detach().cpu().double() - ref).pow(2).sum())
+        num32 += float((g32[k].double() - ref).pow(2).sum())
+        den += float(ref.pow(2).sum())
+    err, noise = (num / den) ** 0.5, (num32 / den) ** 0.5
+    assert err < max(5e-3, 4 * noise), (err, noise)   # global relative L2 of all gradients vs the CPU-fp32 noise
