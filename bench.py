@@ -293,6 +293,8 @@ def main():
                        "train_conv_gflop_per_img": round(3 * fwd_flops_img / 1e9, 1)},
             "final_loss_sum": loss,
             "achieved_conv_tflops": round(3 * fwd_flops_img * value / 1e12, 2),
+            # MFMA-only fraction of the step = (sum of conv FLOPs / dense MFMA peak) / measured step time
+            "mfma_only_frac_of_step": round(3 * fwd_flops_img * value / 1e12 / (world * PEAK_MFMA_TFLOPS[c["dtype"]]), 4),
             "roofline": roof,
         }
         if table and args.table:
