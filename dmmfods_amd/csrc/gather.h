@@ -299,10 +299,12 @@ __device__ __forceinline__ f16x8 bn_relu_slot(const f16x8& x, const SlotK<8>& k)
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xi[p]), "v"(k.k0[2 * p]), "v"(k.k1[2 * p]));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "+v"(d) : "v"(xi[p]), "v"(k.k0[2 * p + 1]), "v"(k.k1[2 * p + 1]));
+    // ReLU on the packed pair; written as the instruction itself because fmax() on a value the compiler cannot see through
+    // comes with a canonicalising v_pk_max_f16 x, x in front of it
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(d) : "v"(d));
     o[p] = d;
   }
-  const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  return __builtin_elementwise_max(__builtin_bit_cast(f16x8, o), z);
+  return __builtin_bit_cast(f16x8, o);
 }
 __device__ __forceinline__ f32x4 bn_relu_slot(const f32x4& x, const SlotK<4>& k) {
   f32x4 o;
