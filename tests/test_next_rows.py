@@ -104,6 +104,10 @@ def test_agent_trains_validates_and_resumes(tmp_path):
     assert not torch.equal(w0, agent.model.param_arena)
     assert abs(agent.optimizer.param_groups[0]["lr"] - 1e-3 * 0.1 ** 2) < 1e-12
     ck_dir = cfg.dir.current_run.checkpoints
+    # as in the reference (A:96-122) an epoch that improves the validation IoU is saved under the best-checkpoint name INSTEAD of
+    # checkpoint.pth.tar, so which files exist after two epochs depends on the data; every epoch leaves one of the two
+    assert any(os.path.isfile(os.path.join(ck_dir, f)) for f in ("checkpoint.pth.tar", cfg.agent.best_checkpoint_name))
+    agent.save_checkpoint()                                # the final state, deterministically under the default name
     assert os.path.isfile(os.path.join(ck_dir, "checkpoint.pth.tar"))
     ck = torch.load(os.path.join(ck_dir, "checkpoint.pth.tar"), map_location="cpu")
     assert set(ck) == {"epoch", "train_iteration", "val_iteration", "best_val_iou", "state_dict", "optimizer"}
