@@ -35,6 +35,12 @@ EVENT_PASSES = 3
 PEAK_HBM_GBS = 8000.0
 
 
+def metric_label(c):
+    """BASELINE.json's metric for the 1280x1920 RGB+LiDAR configs; the other configs say what they measured."""
+    inputs = "RGB+LiDAR" if c["s2"] else "RGB"
+    return f"training images/sec at {c['H']}x{c['W']} {inputs}"
+
+
 def make_config(c):
     from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
     cfg = get_config("/tmp/dmmfods_bench")
@@ -206,7 +212,7 @@ def main():
     from dmmfods_amd import _lib
     from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
     from dmmfods_amd.optim import FusedAdam
-    from dmmfods_amd.parallel import GradAllReduce
+    from dmmfods_amd.parallel import GradAllReduce, broadcast_parameters
 
     c = dict(CONFIGS[args.config])
     if args.dtype:
@@ -216,15 +222,22 @@ def main():
     torch.manual_seed(123)  # identical weights on every rank (reference agent seed, H:179)
     model = Dense_U_Net_lidar(make_config(c), compute_dtype=c["dtype"]).to(device).train()
     opt = FusedAdam(model)
-    reducer = GradAllReduce(model) if distributed else None
+    force = world == 1 and distributed  # DMM_FORCE_DIST: the N > 1 code path, collectives included, on one GPU
+    reducer = GradAllReduce(model, force=force) if distributed else None
+    if distributed:
+        broadcast_parameters(model, src=0, force=force)   # every rank starts from rank 0's weights and running statistics
     rgb, lidar, tgt = synthetic_batch(c, device, seed=rank)
+    overlap_comm = not os.environ.get("DMM_NO_COMM_OVERLAP")
 
     def step():
         with torch.no_grad():
             model(rgb, lidar)
-        met = model.loss_backward(tgt)
+        met = model.loss_backward(tgt)      # enqueues the whole backward; returns before the GPU has run it
         if reducer is not None:
-            reducer.all_reduce()
+            if overlap_comm:                # one all-reduce per gradient bucket, each behind the bucket's readiness event
+                GradAllReduce.wait(reducer.reduce_overlapped())
+            else:
+                reducer.all_reduce()
         opt.step()
         return met
 
@@ -282,7 +295,7 @@ def main():
                     print(f"{ms_:9.3f} ms  {lab:48s} {fl / ms_ / 1e9 if ms_ else 0:8.1f} TF/s {by / ms_ / 1e6 if ms_ else 0:8.1f} GB/s", file=sys.stderr)
         fwd_flops_img = plan.flops_forward / c["batch"]
         out = {
-            "metric": "training images/sec at 1280x1920 RGB+LiDAR",
+            "metric": metric_label(c),
             "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if c["dtype"] == "fp16" else "f32", "data": "synthetic",

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMM_LIB_PATH") or os.path.join(_HERE, "libdmmfods_hip.so")  # DMM_LIB_PATH: experiment builds
 
 DMM_F32, DMM_F16 = 0, 1
+LOSS_BCE, LOSS_FOCAL = 0, 1
 T_CONV, T_CONVT, T_BN_WEIGHT, T_BN_BIAS, T_BN_MEAN, T_BN_VAR, T_BN_TRACKED = range(7)
 ERR_INVALID, ERR_SHAPE, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 
@@ -74,6 +75,11 @@ def lib():
     L.dmm_plan_loss_backward.argtypes = [vp, vp, vp, vp, vp]
     L.dmm_plan_backward.argtypes = [vp, vp, vp]
     L.dmm_plan_loss_metrics.argtypes = [vp, vp, vp, vp, vp]
+    L.dmm_plan_set_loss.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.dmm_loss_forward.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.dmm_plan_num_grad_buckets.argtypes = [vp]
+    L.dmm_plan_grad_bucket.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.dmm_plan_grad_bucket_wait.argtypes = [vp, C.c_int, vp]
     L.dmm_plan_profile_begin.argtypes = [vp, C.c_int]
     L.dmm_plan_profile_filter.restype = C.c_int
     L.dmm_plan_profile_filter.argtypes = [vp, C.c_char_p]
@@ -94,7 +100,8 @@ EXPORTS = [
     "dmm_last_error", "dmm_version", "dmm_set_option", "dmm_plan_create", "dmm_plan_destroy", "dmm_plan_num_tensors",
     "dmm_plan_tensor_info", "dmm_plan_num_params", "dmm_plan_num_buffer_elems", "dmm_plan_workspace_bytes",
     "dmm_plan_forward_flops", "dmm_plan_bind", "dmm_plan_forward", "dmm_plan_loss_backward", "dmm_plan_backward",
-    "dmm_plan_loss_metrics", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
+    "dmm_plan_loss_metrics", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
+    "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
     "dmm_conv_dgrad",
 ]

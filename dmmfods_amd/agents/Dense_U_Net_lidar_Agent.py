@@ -51,13 +51,18 @@ class _StepLR:
 
 
 class Dense_U_Net_lidar_Agent:
-    def __init__(self, config=None, torchvision_init=True, compute_dtype=None, data_loader=None):
+    def __init__(self, config=None, torchvision_init=True, compute_dtype=None, data_loader=None, loss=None):
         self.logger = logging.getLogger("Agent")
         # the reference always builds DenseNet-121 (A:44); torchvision_init=True would download ImageNet weights (no network)
         self.model = densenet121_u_lidar(pretrained=False, config=config, compute_dtype=compute_dtype)
         self.config = self.model.config
         self.data_loader = data_loader if data_loader is not None else WaymoDataset_Loader(self.config)
-        self.loss = torch.nn.BCEWithLogitsLoss(reduction="none")  # kept for API parity; the step uses the fused tail
+        # A:54.  The step uses the fused tail; a FocalLoss / ClassWiseFocalLoss (reference L:9-91) becomes its loss epilogue.
+        self.loss = loss if loss is not None else torch.nn.BCEWithLogitsLoss(reduction="none")
+        if hasattr(self.loss, "attach"):
+            self.loss.attach(self.model)
+        elif not isinstance(self.loss, torch.nn.BCEWithLogitsLoss):
+            raise ValueError("loss must be BCEWithLogitsLoss(reduction='none') or a dmmfods_amd focal loss")
         o = self.config.optimizer
         self.optimizer = FusedAdam(self.model, lr=o.learning_rate, betas=(o.beta1, o.beta2), eps=o.eps,
                                    weight_decay=o.weight_decay, amsgrad=o.amsgrad)

@@ -26,6 +26,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 static bool g_overlap_wgrad = getenv("DMM_NO_OVERLAP") == nullptr;
+static int g_bucket_mb = getenv("DMM_GRAD_BUCKET_MB") ? atoi(getenv("DMM_GRAD_BUCKET_MB")) : 25;
 
 extern "C" {
 
@@ -36,6 +37,11 @@ int dmm_set_option(const char* name, int value) {
   if (!name) return fail(DMM_ERR_INVALID, "null argument");
   if (std::string(name) == "overlap_wgrad") { g_overlap_wgrad = value != 0; return DMM_OK; }
   if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
+  if (std::string(name) == "grad_bucket_mb") {  // applies to plans created afterwards; 0 = one bucket
+    if (value < 0) return fail(DMM_ERR_INVALID, "grad_bucket_mb must be >= 0");
+    g_bucket_mb = value;
+    return DMM_OK;
+  }
   return fail(DMM_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -47,6 +53,7 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   if (!(desc->loss_scale > 0)) return fail(DMM_ERR_INVALID, "loss_scale must be > 0");
   dmm_plan* p = new dmm_plan();
   p->desc = *desc;
+  p->bucket_bytes = (size_t)g_bucket_mb << 20;
   try {
     plan_build_tables(p);
   } catch (const std::domain_error& e) {
@@ -63,6 +70,7 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
 void dmm_plan_destroy(dmm_plan* plan) {
   if (!plan) return;
   for (void* e : plan->fork_events) hipEventDestroy((hipEvent_t)e);
+  for (void* e : plan->bucket_events) hipEventDestroy((hipEvent_t)e);
   for (void* e : plan->join_events) hipEventDestroy((hipEvent_t)e);
   for (void* s2 : plan->side_streams) hipStreamDestroy((hipStream_t)s2);
   delete plan;
@@ -106,7 +114,10 @@ int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float
   return DMM_OK;
 }
 
-static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_which = -1, size_t ev_offset = 0) {
+// Launches ops[begin, end) in order (end = 0: to the end of the list).
+static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_which = -1, size_t begin = 0, size_t end = 0) {
+  if (end == 0 || end > ops.size()) end = ops.size();
+  const size_t ev_offset = 0;
   const int dt = p->desc.dtype;
   const bool mfma = p->desc.use_mfma != 0;
   std::vector<void*>* evs = nullptr;
@@ -154,7 +165,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       forked = false;
     }
   };
-  for (size_t i = 0; i < ops.size(); ++i) {
+  for (size_t i = begin; i < end; ++i) {
     Op& o = ops[i];
     hipError_t e = hipSuccess;
     // side-stream launches: weight gradients and the leaves of the backward graph (stem, raw-input branches)
@@ -171,7 +182,6 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       hipStreamWaitEvent(lst, fe, 0);
       forked = true;
     }
-    if (o.kind == OP_UNPACK) join();
     const bool sel = selected(o);
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], lst);
     switch (o.kind) {
@@ -188,10 +198,19 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, lst); break;
       case OP_APPLYCORR: e = launch_apply_corr(o.ac, dt, lst); break;
       case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, lst); break;
-      default: return fail(DMM_ERR_STATE, "unknown op");
+      default: join(); return fail(DMM_ERR_STATE, "unknown op");
     }
+    if (e != hipSuccess) join();  // leave the main stream ordered after whatever the side stream already got
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], lst);
+    if (o.signal >= 0) {  // a gradient bucket is final on this stream from here on
+      while ((int)p->bucket_events.size() <= o.signal) {
+        hipEvent_t be;
+        if (hipEventCreateWithFlags(&be, hipEventDisableTiming) != hipSuccess) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
+        p->bucket_events.push_back((void*)be);
+      }
+      hipEventRecord((hipEvent_t)p->bucket_events[o.signal], lst);
+    }
   }
   join();
   return DMM_OK;
@@ -212,12 +231,45 @@ int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_
   return run_ops(plan, ops, (hipStream_t)stream, training ? 0 : -1);
 }
 
+static void set_loss_fields(const dmm_plan* plan, BceArgs& a) {
+  a.kind = plan->loss_kind;
+  for (int i = 0; i < 8; ++i) { a.alpha[i] = plan->loss_alpha[i]; a.gamma[i] = plan->loss_gamma[i]; }
+}
+
+int dmm_plan_set_loss(dmm_plan* plan, int kind, const float* alpha, const float* gamma, int nclass) {
+  if (!plan) return fail(DMM_ERR_INVALID, "null plan");
+  if (kind != DMM_LOSS_BCE && kind != DMM_LOSS_FOCAL) return fail(DMM_ERR_INVALID, "loss kind must be DMM_LOSS_BCE or DMM_LOSS_FOCAL");
+  if (kind == DMM_LOSS_FOCAL) {
+    if (!alpha || !gamma || nclass != plan->desc.num_classes) return fail(DMM_ERR_INVALID, "focal loss needs num_classes alpha / gamma values");
+    for (int i = 0; i < nclass; ++i) { plan->loss_alpha[i] = alpha[i]; plan->loss_gamma[i] = gamma[i]; }
+  }
+  plan->loss_kind = kind;
+  return DMM_OK;
+}
+
+int dmm_loss_forward(int kind, int from_prob, const float* alpha, const float* gamma, const float* input, const float* target,
+                     float* loss_out, float* dinput_out, int batch, int nclass, int height, int width, void* stream) {
+  if (!input || !target || (!loss_out && !dinput_out)) return fail(DMM_ERR_INVALID, "null argument");
+  if (kind != DMM_LOSS_BCE && kind != DMM_LOSS_FOCAL) return fail(DMM_ERR_INVALID, "loss kind must be DMM_LOSS_BCE or DMM_LOSS_FOCAL");
+  if (nclass < 1 || nclass > 8 || batch < 1 || height < 1 || width < 1) return fail(DMM_ERR_INVALID, "1..8 classes (dim 1) supported");
+  if (kind == DMM_LOSS_FOCAL && (!alpha || !gamma)) return fail(DMM_ERR_INVALID, "focal loss needs alpha / gamma");
+  BceArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = input; a.target = target; a.loss_out = loss_out; a.dx_out = dinput_out;
+  a.B = batch; a.NC = nclass; a.H = height; a.W = width;
+  a.thr = 0.f; a.loss_scale = 1.f; a.kind = kind; a.from_prob = from_prob ? 1 : 0;
+  for (int i = 0; i < nclass; ++i) { a.alpha[i] = alpha ? alpha[i] : 1.f; a.gamma[i] = gamma ? gamma[i] : 2.f; }
+  HIPCHK(launch_bce_metrics(a, DT_F32, (hipStream_t)stream));
+  return DMM_OK;
+}
+
 int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream) {
   if (!plan || !plan->bound) return fail(DMM_ERR_STATE, "plan not bound");
   if (!logits || !target) return fail(DMM_ERR_INVALID, "null argument");
   Op& b = plan->bwd[plan->bce_op];
   b.bce.logits = logits;
   b.bce.target = target;
+  set_loss_fields(plan, b.bce);
   int rc = run_ops(plan, plan->bwd, (hipStream_t)stream, 1);
   if (rc) return rc;
   if (metrics_out) HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -233,10 +285,32 @@ int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream) {
   memset(&cv, 0, sizeof(cv));
   cv.src1 = dlogits; cv.C1 = b.NC; cv.dst = b.dlogits; cv.B = b.B; cv.H = b.H; cv.W = b.W;
   cv.scale = plan->desc.loss_scale;
-  HIPCHK(hipMemsetAsync(plan->bwd[0].ms.p, 0, plan->bwd[0].ms.bytes, st));
+  // everything the fused path runs in front of the loss kernel (backward accumulators AND the gradient arena: unpack adds
+  // into it for merged-tap / shared-master weights), then the external d(loss)/d(logit) instead of the loss kernel
+  int rc = run_ops(plan, plan->bwd, st, -1, 0, (size_t)plan->bce_op);
+  if (rc) return rc;
   HIPCHK(launch_convert_input(cv, plan->desc.dtype, st));
-  std::vector<Op> rest(plan->bwd.begin() + plan->bce_op + 1, plan->bwd.end());
-  return run_ops(plan, rest, st);
+  return run_ops(plan, plan->bwd, st, -1, (size_t)plan->bce_op + 1, 0);
+}
+
+int dmm_plan_num_grad_buckets(const dmm_plan* plan) { return plan ? (int)plan->buckets.size() : 0; }
+
+int dmm_plan_grad_bucket(const dmm_plan* plan, int index, int64_t* offset, int64_t* count) {
+  if (!plan || index < 0 || index >= (int)plan->buckets.size()) return fail(DMM_ERR_INVALID, "bucket index out of range");
+  if (offset) *offset = plan->buckets[index].off;
+  if (count) *count = plan->buckets[index].n;
+  return DMM_OK;
+}
+
+int dmm_plan_grad_bucket_wait(dmm_plan* plan, int index, void* stream) {
+  if (!plan || index < 0 || index >= (int)plan->buckets.size()) return fail(DMM_ERR_INVALID, "bucket index out of range");
+  const GradBucket& b = plan->buckets[index];
+  for (int ev : {b.ev_main, b.ev_side}) {
+    if (ev < 0) continue;
+    if (ev >= (int)plan->bucket_events.size()) return fail(DMM_ERR_STATE, "no backward pass has been enqueued on this plan yet");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)plan->bucket_events[ev], 0));
+  }
+  return DMM_OK;
 }
 
 int dmm_plan_profile_begin(dmm_plan* plan, int max_passes) {
@@ -298,6 +372,7 @@ int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* targ
   Op o = plan->bce_only;
   o.bce.logits = logits;
   o.bce.target = target;
+  set_loss_fields(plan, o.bce);
   HIPCHK(launch_bce_metrics(o.bce, plan->desc.dtype, st));
   HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, st));
   return DMM_OK;

@@ -13,6 +13,7 @@
 //     per-channel affine term (q + r*x) is applied by whoever reads that gradient next.
 #include "plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -555,6 +556,7 @@ struct Builder {
 
   void emit_bn_bwd_finalize(int bn) {
     Bn& b = bns[bn];
+    const size_t first_op = ops->size();
     for (auto& rg : b.ranges) {
       const bool outer = leaf_scope;
       leaf_scope = outer || is_raw_input(rg.buf);
@@ -574,6 +576,7 @@ struct Builder {
       a.grad_scale = 1.0f / d.loss_scale;
       a.C = rg.n;
     }
+    bn_grad_done(bn, first_op);
     for (auto& rg : b.ranges) {
       Buf& sb = bufs[rg.buf];
       if (!(rg.want_qr && sb.q && sb.matz) || sb.materialized) continue;
@@ -631,6 +634,7 @@ struct Builder {
             (src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
+    conv_grad_done(c);
     // ---- data gradients with fused BN+ReLU backward ----
     for (int s = 0; s < c.nseg; ++s) {
       SegRec& sr = c.seg[s];
@@ -987,6 +991,101 @@ struct Builder {
     tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
   }
 
+  // ---------------------------------------------------------------- gradient buckets (data-parallel overlap)
+  struct BucketRec {
+    int64_t off = 0, n = 0;
+    int convs_left = 0, bns_left = 0;
+    int first_desc = 0, ndesc = 0, rows = 0;
+    int last_main = -1, last_side = -1;
+  };
+  std::vector<BucketRec> brecs;
+  PackDesc* unpack_dev = nullptr;
+  int* unprefix_dev = nullptr;
+  int bucket_of(int64_t off) const {
+    for (size_t b = 0; b < brecs.size(); ++b)
+      if (off >= brecs[b].off && off < brecs[b].off + brecs[b].n) return (int)b;
+    throw std::runtime_error("gradient offset outside every bucket");
+  }
+  void make_buckets() {
+    // whole tensors in .parameters() order, closed once they reach the target size
+    brecs.clear();
+    const int64_t target = (int64_t)(P.bucket_bytes / 4);
+    BucketRec cur;
+    std::string group;
+    for (auto& t : P.tensors) {
+      if (t.kind > DMM_T_BN_BIAS) continue;
+      int64_t n = 1;
+      for (int k = 0; k < t.ndim; ++k) n *= t.shape[k];
+      // the top-level modules (features, decoder, head, stream_2_features, concat_module) finish at very different times:
+      // do not let a sizeable bucket run across such a boundary
+      const std::string grp = t.name.substr(0, t.name.find('.'));
+      if (target > 0 && grp != group && cur.n * 4 >= (4 << 20)) { brecs.push_back(cur); cur = BucketRec(); }
+      group = grp;
+      if (cur.n == 0) cur.off = t.off;
+      cur.n += n;
+      if (target > 0 && cur.n >= target) { brecs.push_back(cur); cur = BucketRec(); }
+    }
+    if (cur.n > 0) brecs.push_back(cur);
+    for (auto& c : convs) brecs[bucket_of(T(c.wname).off)].convs_left++;
+    for (auto& b : bns) brecs[bucket_of(b.dgamma - P.grads)].bns_left++;
+    // unpack tables: the descriptors that scatter into a master gradient, grouped by bucket
+    P.unpacks.clear(); P.unpack_prefix.clear();
+    for (size_t bi = 0; bi < brecs.size(); ++bi) {
+      BucketRec& bk = brecs[bi];
+      bk.first_desc = (int)P.unpacks.size();
+      bk.rows = 0;
+      for (auto& pd : P.packs) {
+        if (pd.gw == nullptr || pd.dpack == nullptr || bucket_of(pd.gw - P.grads) != (int)bi) continue;
+        P.unpack_prefix.push_back(bk.rows);
+        int chunks = 0;
+        for (int s2 = 0; s2 < pd.nseg; ++s2) chunks += pd.seg[s2].nchunks;
+        bk.rows += chunks * pd.Npad;
+        P.unpacks.push_back(pd);
+      }
+      bk.ndesc = (int)P.unpacks.size() - bk.first_desc;
+    }
+    unpack_dev = wptr<PackDesc>(P.packs.size() + 1);  // sized by the pack count: identical in the sizing and the bound pass
+    unprefix_dev = wptr<int>(P.packs.size() + 1);
+  }
+  void note_write(int b, int op_index) {
+    const Op& o = (*ops)[op_index];
+    if (o.kind == OP_WGRAD || o.kind == OP_UNPACK || o.leaf) brecs[b].last_side = op_index; else brecs[b].last_main = op_index;
+  }
+  void conv_grad_done(const ConvRec& c) {  // called behind the weight-gradient launch(es) of a convolution
+    const int b = bucket_of(T(c.wname).off);
+    BucketRec& bk = brecs[b];
+    if (--bk.convs_left > 0 || bk.ndesc == 0) return;
+    // the bucket's last weight gradient: scatter its packed gradients into the arena right behind it (same stream)
+    Op& o = push(OP_UNPACK);
+    o.leaf = 1;
+    o.pk.descs = unpack_dev + bk.first_desc;
+    o.pk.prefix = unprefix_dev + bk.first_desc;
+    o.pk.ndesc = bk.ndesc;
+    o.pk.total_rows = bk.rows;
+    o.pk.grad_scale = 1.0f / d.loss_scale;
+    tag(o, "unpack", "weights", 0, (double)bk.n * (4.0 + 4.0));
+    note_write(b, (int)ops->size() - 1);
+  }
+  void bn_grad_done(int bn, size_t first_op) {  // called behind the bn_bwd_finalize launches [first_op, end) of a BatchNorm
+    const int b = bucket_of(bns[bn].dgamma - P.grads);
+    brecs[b].bns_left--;
+    for (size_t i = first_op; i < ops->size(); ++i) note_write(b, (int)i);
+  }
+  void finish_buckets() {
+    P.buckets.clear();
+    int nev = 0;
+    for (auto& bk : brecs) {
+      if (bk.convs_left != 0 || bk.bns_left != 0) throw std::runtime_error("gradient bucket bookkeeping is inconsistent");
+      GradBucket gb;
+      gb.off = bk.off; gb.n = bk.n;
+      if (bk.last_main >= 0) { gb.ev_main = nev++; (*ops)[bk.last_main].signal = gb.ev_main; }
+      if (bk.last_side >= 0) { gb.ev_side = nev++; (*ops)[bk.last_side].signal = gb.ev_side; }
+      gb.ready = std::max(bk.last_main, bk.last_side);
+      P.buckets.push_back(gb);
+    }
+    std::stable_sort(P.buckets.begin(), P.buckets.end(), [](const GradBucket& a, const GradBucket& b) { return a.ready < b.ready; });
+  }
+
   bool pad_pitch = getenv("DMM_PITCH_PAD") != nullptr;  // measured: no effect on MI355X for this access pattern; off
   PackDesc* pack_dev = nullptr;
   int* prefix_dev = nullptr;
@@ -1007,6 +1106,7 @@ struct Builder {
     P.metrics_bytes = (size_t)(2 * g.nc + (size_t)d.batch * 2 * g.nc) * sizeof(double);
     P.metrics = zbptr<double>(P.metrics_bytes / sizeof(double));
 
+    make_buckets();
     std::vector<Op> dummy;
     // ---- training forward ----
     ops = sizing ? &dummy : &P.fwd_train;
@@ -1039,6 +1139,7 @@ struct Builder {
       a.out = P.metrics;
       a.B = d.batch; a.NC = g.nc; a.H = d.height; a.W = d.width;
       a.thr = d.iou_threshold; a.loss_scale = d.loss_scale;
+      a.metrics = 1;
       tag(o, "bce", "loss", 0, (double)a.B * a.H * a.W * (a.NC * 8.0 + 8.0 * esz));
       P.bce_op = (int)ops->size() - 1;
       P.bce_only = o;
@@ -1048,7 +1149,7 @@ struct Builder {
     for (int i = (int)recs.size() - 1; i >= 0; --i) {
       if (recs[i].type == 0) emit_conv_bwd(convs[recs[i].idx]); else emit_pool_bwd(pools[recs[i].idx]);
     }
-    emit_pack_op(OP_UNPACK);
+    finish_buckets();
   }
 };
 
@@ -1088,4 +1189,8 @@ void plan_bind(dmm_plan* p, void* ws) {
   // upload the pack tables
   hipMemcpy(b.pack_dev, p->packs.data(), p->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   hipMemcpy(b.prefix_dev, p->pack_prefix.data(), p->pack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (!p->unpacks.empty()) {
+    hipMemcpy(b.unpack_dev, p->unpacks.data(), p->unpacks.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+    hipMemcpy(b.unprefix_dev, p->unpack_prefix.data(), p->unpack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);
+  }
 }

@@ -43,6 +43,7 @@ struct Op {
   int kind;
   int epi;
   int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it)
+  int signal;      // gradient bucket event to record behind this launch on the stream it ran on (-1: none)
   double flops;    // algorithmic 2*MACs of this launch (reference formulation)
   double bytes;    // algorithmic HBM bytes: every operand read once, every result written once
   char label[56];  // kernel class / layer
@@ -60,10 +61,18 @@ struct Op {
     PackArgs pk;
     ApplyCorrArgs ac;
   };
-  Op() : kind(0), epi(0), leaf(0), flops(0), bytes(0) { label[0] = 0; }
+  Op() : kind(0), epi(0), leaf(0), signal(-1), flops(0), bytes(0) { label[0] = 0; }
 };
 
 }  // namespace dmm
+
+// A contiguous range of the gradient arena (whole tensors) whose gradients become final at a known point of the backward
+// launch list: data-parallel training all-reduces it from there on, beside the rest of backward.
+struct GradBucket {
+  int64_t off = 0, n = 0;             // elements of the gradient arena
+  int ev_main = -1, ev_side = -1;     // indices into dmm_plan::bucket_events (-1: nothing on that stream writes the bucket)
+  int ready = -1;                     // index of the last launch that writes into it
+};
 
 struct dmm_plan {
   dmm_model_desc desc;
@@ -81,10 +90,18 @@ struct dmm_plan {
   int logits_op_train = -1, logits_op_eval = -1;
   int bce_op = -1, bce_only_valid = 0;
   dmm::Op bce_only;     // loss + metrics without gradient
+  int loss_kind = 0;          // 0 BCE, 1 focal (dmm_plan_set_loss)
+  float loss_alpha[8] = {1, 1, 1, 1, 1, 1, 1, 1}, loss_gamma[8] = {2, 2, 2, 2, 2, 2, 2, 2};
   double* metrics = nullptr;  // device, inside the zero region
   size_t metrics_bytes = 0;
   std::vector<dmm::PackDesc> packs;
   std::vector<int> pack_prefix;
+  // unpack tables, grouped by gradient bucket
+  std::vector<dmm::PackDesc> unpacks;
+  std::vector<int> unpack_prefix;
+  size_t bucket_bytes = 0;
+  std::vector<GradBucket> buckets;       // in the order they become ready
+  std::vector<void*> bucket_events;      // hipEvent_t, created on first use
   // profiling: per-op events on the launch stream, one set per recorded pass
   int prof_max_passes = 0;
   int prof_pass[2] = {0, 0};                       // passes recorded for [0] training forward, [1] backward

@@ -93,6 +93,14 @@ struct BceArgs {
   double* out;    // [NC loss | NC equal | B x (NC inter, NC union)]
   int B, NC, H, W;
   float thr, loss_scale;
+  // loss epilogue: 0 = BCE-with-logits (A:54); 1 = focal loss alpha[c]*(1-exp(-bce))^gamma[c]*bce on top of it
+  // (reference graphs/losses/FocalLoss.py:41-50, class-wise :78-91).  from_prob: the input holds probabilities
+  // (binary_cross_entropy with torch's log clamp at -100) instead of logits.
+  int kind, from_prob;
+  float alpha[8], gamma[8];
+  float* loss_out;  // fp32 NCHW unreduced loss (nullable)
+  float* dx_out;    // fp32 NCHW d(sum loss)/d(input), unscaled (nullable)
+  int metrics;      // 0: skip the loss sums / metric counts (out may be null)
 };
 
 struct ApplyCorrArgs {

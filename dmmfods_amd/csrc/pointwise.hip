@@ -316,6 +316,30 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
 
 // ---------------------------------------------------------------------------------------------------
 // out[] (doubles): [0..NC) loss sums, [NC..2NC) equal counts, then per image b: inter[NC], union[NC]
+// Per-element loss and its derivative.  kind 0: BCE; kind 1: focal  F = alpha*(1-pt)^gamma*bce with pt = exp(-bce), so
+// dF/dx = alpha*(1-pt)^(gamma-1) * bce' * (gamma*pt*bce + (1-pt))   (d(1-pt)/dx = pt*bce').
+__device__ __forceinline__ void loss_elem(const BceArgs& a, int n, float x, float t, float& loss, float& dx) {
+  float bce, dbce;
+  if (!a.from_prob) {
+    const float e = expf(-fabsf(x));
+    bce = fmaxf(x, 0.f) - x * t + log1pf(e);
+    const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dbce = sig - t;
+  } else {  // torch.binary_cross_entropy: logs clamped at -100
+    const float lp = fmaxf(logf(x), -100.f), lq = fmaxf(logf(1.f - x), -100.f);
+    bce = -(t * lp + (1.f - t) * lq);
+    dbce = -(t * (lp > -100.f ? 1.f / x : 0.f) - (1.f - t) * (lq > -100.f ? 1.f / (1.f - x) : 0.f));
+  }
+  if (a.kind == 0) { loss = bce; dx = dbce; return; }
+  const float al = a.alpha[n], ga = a.gamma[n];
+  const float omp = -expm1f(-bce);  // 1 - pt, without cancellation for small bce
+  const float pt = 1.f - omp;
+  if (!(omp > 0.f)) { loss = 0.f; dx = 0.f; return; }
+  const float pw1 = powf(omp, ga - 1.f);
+  loss = al * pw1 * omp * bce;
+  dx = al * pw1 * dbce * fmaf(ga * pt, bce, omp);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bce_metrics_kernel(BceArgs a) {
   __shared__ float red[4 * 8];
@@ -334,10 +358,12 @@ __global__ __launch_bounds__(256) void bce_metrics_kernel(BceArgs a) {
       if (n < a.NC) {
         const size_t idx = ((size_t)b * a.NC + n) * plane + p;
         const float x = a.logits[idx], t = a.target[idx];
-        const float e = expf(-fabsf(x));
-        ls[n] += fmaxf(x, 0.f) - x * t + log1pf(e);
-        const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-        g[n] = (sig - t) * a.loss_scale;
+        float l, d;
+        loss_elem(a, n, x, t, l, d);
+        ls[n] += l;
+        g[n] = d * a.loss_scale;
+        if (a.loss_out != nullptr) a.loss_out[idx] = l;
+        if (a.dx_out != nullptr) a.dx_out[idx] = d;
         const bool pp = x >= a.thr, gg = t >= a.thr;
         eq[n] += (pp == gg) ? 1.f : 0.f;
         in_[n] += (pp && gg) ? 1.f : 0.f;
@@ -350,6 +376,7 @@ __global__ __launch_bounds__(256) void bce_metrics_kernel(BceArgs a) {
       for (int n = 0; n < 8; ++n) d[n] = from_f32<T>(g[n]);
     }
   }
+  if (!a.metrics) return;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     if (n >= a.NC) break;

@@ -76,6 +76,13 @@ class _Plan:
         self.flops_forward = L.dmm_plan_forward_flops(self.handle)
         _lib.check(L.dmm_plan_bind(self.handle, self.workspace.data_ptr(), nbytes, model._param_arena.data_ptr(),
                                    model._grad_arena.data_ptr(), model._buffer_arena.data_ptr()))
+        self.loss_key = None
+        # gradient buckets in the order backward finishes them: (offset, count) in elements of the gradient arena
+        self.grad_buckets = []
+        for i in range(L.dmm_plan_num_grad_buckets(self.handle)):
+            off, cnt = C.c_int64(), C.c_int64()
+            _lib.check(L.dmm_plan_grad_bucket(self.handle, i, C.byref(off), C.byref(cnt)))
+            self.grad_buckets.append((off.value, cnt.value))
 
     def __del__(self):
         try:
@@ -185,6 +192,37 @@ class Dense_U_Net_lidar(nn.Module):
         self.num_params = sum(p.numel() for p in self.parameters())
         self._plans = OrderedDict()
         self._last = None
+        self._loss = (_lib.LOSS_BCE, None, None)
+
+    # ------------------------------------------------------------------ loss epilogue
+    def set_loss(self, kind="bce", alpha=None, gamma=None):
+        """Loss computed by loss_backward() / loss_metrics(): "bce" = BCEWithLogitsLoss(reduction='none') (reference A:54);
+        "focal" = alpha*(1-exp(-bce))**gamma*bce with scalar or per-class alpha / gamma (reference L:9-91)."""
+        if kind == "bce":
+            self._loss = (_lib.LOSS_BCE, None, None)
+            return self
+        if kind != "focal":
+            raise ValueError("loss kind must be 'bce' or 'focal'")
+        nc = int(self.num_classes)
+
+        def per_class(v, default):
+            v = default if v is None else v
+            v = [float(v)] * nc if not hasattr(v, "__len__") else [float(e) for e in v]
+            if len(v) != nc:
+                raise ValueError(f"need {nc} per-class values")
+            return tuple(v)
+        self._loss = (_lib.LOSS_FOCAL, per_class(alpha, 1.0), per_class(gamma, 2.0))
+        return self
+
+    def _apply_loss(self, plan):
+        if plan.loss_key == self._loss:
+            return
+        kind, alpha, gamma = self._loss
+        nc = int(self.num_classes)
+        a = (C.c_float * nc)(*(alpha or [1.0] * nc))
+        g = (C.c_float * nc)(*(gamma or [2.0] * nc))
+        _lib.check(_lib.lib().dmm_plan_set_loss(plan.handle, kind, a, g, nc))
+        plan.loss_key = self._loss
 
     # ------------------------------------------------------------------ parameters
     def _init_weights(self):
@@ -282,7 +320,8 @@ class Dense_U_Net_lidar(nn.Module):
                                                logits.data_ptr(), 1 if self.training else 0, _lib.stream_ptr()))
         if self.training:
             self._tracked_arena += 1
-        self._last = (plan, logits)
+        # loss_backward() needs the saved activations / batch statistics of a TRAINING forward of this very plan
+        self._last = (plan, logits) if self.training else None
         if self.training and torch.is_grad_enabled():
             return _HipBackward.apply(self._hook, logits, self, plan)
         return logits
@@ -294,6 +333,7 @@ class Dense_U_Net_lidar(nn.Module):
             raise RuntimeError("loss_backward() needs a preceding training-mode forward()")
         plan, logits = self._last
         t = target.contiguous().float()
+        self._apply_loss(plan)
         _lib.check(_lib.lib().dmm_plan_loss_backward(plan.handle, logits.data_ptr(), t.data_ptr(), plan.metrics.data_ptr(),
                                                      _lib.stream_ptr()))
         self._attach_grads()
@@ -304,9 +344,24 @@ class Dense_U_Net_lidar(nn.Module):
         plan = self._get_plan(logits.shape[0], logits.shape[2], logits.shape[3])
         t = target.contiguous().float()
         lg = logits.detach().contiguous().float()
+        self._apply_loss(plan)
         _lib.check(_lib.lib().dmm_plan_loss_metrics(plan.handle, lg.data_ptr(), t.data_ptr(), plan.metrics.data_ptr(),
                                                     _lib.stream_ptr()))
         return self._metrics(plan, logits.shape)
+
+    # ------------------------------------------------------------------ data-parallel hooks
+    def grad_buckets(self):
+        """[(offset, count)] ranges of grad_arena in the order the last training forward's plan finishes them in backward."""
+        if self._last is None:
+            raise RuntimeError("grad_buckets() needs a preceding training-mode forward()")
+        return list(self._last[0].grad_buckets)
+
+    def grad_bucket_wait(self, index, stream=None):
+        """Make `stream` (default: the current stream) wait until bucket `index` of the enqueued backward is final."""
+        if self._last is None:
+            raise RuntimeError("grad_bucket_wait() needs a preceding training-mode forward()")
+        sp = _lib.stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(_lib.lib().dmm_plan_grad_bucket_wait(self._last[0].handle, int(index), sp))
 
     def _metrics(self, plan, shape):
         B, nc, H, W = shape

@@ -11,6 +11,7 @@
  *   dmm_plan_forward ..................... Dense_U_Net_lidar.forward    graphs/models/Dense_U_Net_lidar.py:210-267
  *   dmm_plan_loss_backward ............... BCEWithLogitsLoss(reduction='none') + metrics + backward(ones)
  *                                          agents/Dense_U_Net_lidar_Agent.py:247-264, utils/...helper.py:311-401
+ *   dmm_plan_set_loss / dmm_loss_forward . FocalLoss / ClassWiseFocalLoss  graphs/losses/FocalLoss.py:9-91
  *   dmm_adam_step ........................ torch.optim.Adam.step        agents/Dense_U_Net_lidar_Agent.py:57-61,265
  *   dmm_conv_forward / dmm_conv_wgrad .... single-kernel entry points for unit tests (torch.nn.functional.conv2d,
  *                                          conv_transpose2d as dispatched by the modules built at :72-131)
@@ -69,7 +70,8 @@ const char* dmm_last_error(void);
 int dmm_version(void);
 /* Kernel selection switches for tests and A/B timing: "thin_logits" (1 = gather-once kernel for the heat-map head's last
  * convolution, 0 = generic kernels), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the data-gradient
- * chain, 0 = one stream).  Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32 summation
+ * chain, 0 = one stream), "grad_bucket_mb" (size of the data-parallel gradient buckets of plans created afterwards).
+ * Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32 summation
  * order. */
 int dmm_set_option(const char* name, int value);
 
@@ -102,9 +104,30 @@ int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_
  * metrics_out (device, doubles): [NC loss sums | NC equal-counts | B x (NC intersections, NC unions)]. */
 int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream);
 
+/* Loss epilogue of dmm_plan_loss_backward / dmm_plan_loss_metrics.  DMM_LOSS_BCE (default): BCEWithLogitsLoss(reduction=
+ * 'none'), agents/Dense_U_Net_lidar_Agent.py:54.  DMM_LOSS_FOCAL: alpha[c]*(1 - exp(-bce))**gamma[c]*bce per class c
+ * (graphs/losses/FocalLoss.py:41-50 with equal entries, ClassWiseFocalLoss :78-91 otherwise); nclass = num_classes. */
+enum { DMM_LOSS_BCE = 0, DMM_LOSS_FOCAL = 1 };
+int dmm_plan_set_loss(dmm_plan* plan, int kind, const float* alpha, const float* gamma, int nclass);
+
+/* The same loss kernel without a plan, on any (batch, nclass <= 8, height, width) fp32 NCHW tensors: unreduced loss
+ * (loss_out, nullable) and d(sum of loss)/d(input) (dinput_out, nullable).  from_prob != 0: `input` holds probabilities
+ * (FocalLoss(logits=False): F.binary_cross_entropy, graphs/losses/FocalLoss.py:43-44). */
+int dmm_loss_forward(int kind, int from_prob, const float* alpha, const float* gamma, const float* input, const float* target,
+                     float* loss_out, float* dinput_out, int batch, int nclass, int height, int width, void* stream);
+
 /* Backward from an externally computed d(loss)/d(logit) (B,num_classes,H,W fp32), e.g. from torch autograd of any
  * loss on the returned logits (reference: loss.backward(...), agents/Dense_U_Net_lidar_Agent.py:264). */
 int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream);
+
+/* Data-parallel training (new here; the reference's torch.distributed import, graphs/models/Dense_U_Net_lidar.py:7, is unused):
+ * the gradient arena is cut into buckets of whole tensors (about dmm_set_option("grad_bucket_mb", 25) each, set before
+ * dmm_plan_create) listed in the order in which backward finishes them (head, decoder, block 4 ... stems).
+ * dmm_plan_grad_bucket_wait makes `stream` wait until bucket `index` of the most recently enqueued backward is final, so an
+ * all-reduce enqueued on that stream runs beside the rest of backward. */
+int dmm_plan_num_grad_buckets(const dmm_plan* plan);
+int dmm_plan_grad_bucket(const dmm_plan* plan, int index, int64_t* offset, int64_t* count);
+int dmm_plan_grad_bucket_wait(dmm_plan* plan, int index, void* stream);
 
 /* Per-launch timing with HIP events recorded on the launch stream (used by bench.py for the roofline block).
  * which: 0 = training forward, 1 = loss + backward.  profile_begin(plan, n) arms recording for the next n passes of

@@ -380,16 +380,143 @@ def g5_trace(M, H):
         json.dump(out, f)
 
 
+# ------------------------------------------------------------------ G7 BASELINE architectures that the GPU tests did not cover
+G7_CASES = {  # name -> (densenet, variant, B, H, W, weight seed, data seed)
+    "d121_mid3_64": (121, "mid3", 2, 64, 96, 123, 11),      # C3 architecture (reference factory M:335-347)
+    "d121_mid3_128": (121, "mid3", 1, 128, 192, 123, 12),
+    "d201_mid3_64": (201, "mid3", 1, 64, 96, 77, 13),       # C5 architecture (reference factory M:377-388)
+}
+
+
+def g7_configs(M, H):
+    """One training forward/backward of the reference's DenseNet-121 / -201 mid-fusion factories: logits, loss sums, metrics and
+    a digest of EVERY parameter gradient."""
+    for name, (dn, vname, B, Hh, Ww, wseed, dseed) in G7_CASES.items():
+        arch = variant_arch(R.DENSENETS[dn], vname)
+        cfg = ref_config(H, arch)
+        model = getattr(M, f"densenet{dn}_u_lidar")(pretrained=False, config=cfg)
+        model.load_state_dict(R.make_state(arch, seed=wseed), strict=True)
+        model.train()
+        rgb, lidar, tgt = R.make_inputs(arch, B, Hh, Ww, seed=dseed)
+        pred = model(rgb, lidar)
+        cur = torch.nn.BCEWithLogitsLoss(reduction="none")(pred, tgt)
+        cur.backward(torch.ones_like(cur.detach()))
+        thr = cfg.agent.iou_threshold
+        store = {"logits_full": pred.detach().numpy().copy(),
+                 "loss_per_class": torch.sum(cur.detach(), dim=(0, 2, 3)).numpy().astype(np.float64),
+                 "iou": H.compute_IoU_whole_img_batch(pred.detach(), tgt, thr).numpy().copy(),
+                 "acc": H.compute_accuracy(tgt, pred.detach(), thr).numpy().copy()}
+        for k, p_ in model.named_parameters():
+            put(store, f"grad/{k}", digest(p_.grad, nsample=64))
+        store["meta/case"] = np.frombuffer(json.dumps(dict(densenet=dn, variant=vname, B=B, H=Hh, W=Ww, weight_seed=wseed,
+                                                          data_seed=dseed)).encode(), dtype=np.uint8)
+        path = os.path.join(GOLD, f"g7_{name}.npz")
+        np.savez_compressed(path, **store)
+        print("G7", name, "->", os.path.getsize(path) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------ G6 rows 8(f): focal losses, dataset reader, agent batch metrics
+def g6_frows(M, H):
+    import tempfile
+    from dmmfods.graphs.losses.FocalLoss import ClassWiseFocalLoss, FocalLoss   # reference L:9-91
+    from dmmfods.datasets.WaymoData import WaymoDataset, WaymoDataset_Loader    # reference D:9-213
+    store = {}
+    # ---- focal losses on fixed logits / targets (values and d(sum)/d(input)) ----
+    B, C, Hh, Ww = 2, 3, 16, 24
+    n = B * C * Hh * Ww
+    x = torch.from_numpy(((R._philox_uniform(9, 1, n) - 0.5) * 12.0).astype(np.float32)).reshape(B, C, Hh, Ww)
+    lv = np.array([0.0, 0.0, 0.0, 0.0, 0.3, 0.5, 0.75, 1.0], dtype=np.float32)
+    t = torch.from_numpy(lv[np.minimum((R._philox_uniform(9, 2, n) * 8).astype(np.int64), 7)]).reshape(B, C, Hh, Ww)
+    store["focal/x"], store["focal/t"] = x.numpy().copy(), t.numpy().copy()
+    cases = {"focal_a1_g2": FocalLoss(alpha=1, gamma=2, logits=True, reduce=False),
+             "focal_a025_g15": FocalLoss(alpha=0.25, gamma=1.5, logits=True, reduce=False),
+             "classwise_default": ClassWiseFocalLoss(),
+             "classwise_mixed": ClassWiseFocalLoss(alpha=[1.0, 2.0, 0.5], gamma=[2.0, 1.0, 3.0])}
+    for name, fn in cases.items():
+        xi = x.clone().requires_grad_(True)
+        out = fn(xi, t)
+        out.backward(torch.ones_like(out))
+        store[f"focal/{name}/loss"] = out.detach().numpy().copy()
+        store[f"focal/{name}/dx"] = xi.grad.numpy().copy()
+    store["focal/focal_a1_g2/mean"] = np.array(FocalLoss(alpha=1, gamma=2, logits=True, reduce=True)(x, t).item())
+    store["focal/prob_a1_g2/loss"] = FocalLoss(alpha=1, gamma=2, logits=False, reduce=False)(torch.sigmoid(x), t).numpy().copy()
+    # ---- dataset reader: the reference's WaymoDataset on batched files written here ----
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = sys.modules["easydict"].EasyDict(H.create_config(tmp))
+        cfg.dir.data.root = os.path.join(tmp, "data")
+        cfg.dir.data.file_lists = os.path.join(tmp, "lists")
+        nb, N, hh, ww = 2, 3, 16, 24
+        for mode in ("train", "val"):
+            d = os.path.join(cfg.dir.data.root, mode, "part0")
+            os.makedirs(os.path.join(d, "labels"))
+            for i in range(nb):
+                u = R._philox_uniform(21, 10 * (mode == "val") + i, N * 7 * hh * ww).astype(np.float32).reshape(N, 7, hh, ww)
+                batch = torch.from_numpy(u.copy())
+                batch[:, :4] *= 255.0
+                batch[:, 4:] = (batch[:, 4:] > 0.9).float()
+                torch.save(batch, os.path.join(d, f"batch_{i}.pt"))
+                store[f"data/{mode}/batch_{i}"] = batch.numpy().copy()
+        ds = WaymoDataset("train", cfg)
+        files = sorted(ds.files)
+        store["data/train_files"] = np.frombuffer(json.dumps(files).encode(), dtype=np.uint8)
+        store["data/len"] = np.array(len(ds))
+        for i, f in enumerate(files):
+            img, lid, hm = ds.get_batch(ds.files.index(f))                      # D:87-103
+            store[f"data/get_batch/{i}/image"] = img.numpy().copy()
+            store[f"data/get_batch/{i}/lidar"] = lid.numpy().copy()
+            store[f"data/get_batch/{i}/ht_map"] = hm.numpy().copy()
+        cfg.loader.num_workers = 0
+        cfg.loader.pin_memory = False
+        ld = WaymoDataset_Loader(cfg)                                            # D:160-213
+        store["data/iterations"] = np.array([ld.train_iterations, ld.valid_iterations])
+        first = next(iter(ld.valid_loader))
+        store["data/loader_first_val_shapes"] = np.array([list(v.shape) for v in first])
+    # ---- the agent's per-batch metric block A:247-260 replayed on fixed tensors ----
+    B, C, Hh, Ww = 4, 3, 16, 24
+    n = B * C * Hh * Ww
+    pred = torch.from_numpy(((R._philox_uniform(31, 1, n) - 0.45) * 6.0).astype(np.float32)).reshape(B, C, Hh, Ww).clone()
+    gt = torch.from_numpy((R._philox_uniform(31, 2, n) > 0.8).astype(np.float32)).reshape(B, C, Hh, Ww).clone()
+    pred[1, 2] = -1.0; gt[1, 2] = 0.0          # empty union -> NaN for (sample 1, class 2)
+    pred[3, 0] = -2.0; gt[3, 0] = 0.0          # ... and (sample 3, class 0)
+    pred[:, 1] = -3.0; gt[:, 1] = 0.0          # class 1 empty in every sample: nan-mean of all-NaN -> NaN -> 0 (A:254)
+    thr = 0.7
+    loss = torch.nn.BCEWithLogitsLoss(reduction="none")(pred, gt)                # A:54, A:247
+    store["agent/pred"], store["agent/gt"] = pred.numpy().copy(), gt.numpy().copy()
+    store["agent/loss_per_class"] = torch.sum(loss, dim=(0, 2, 3)).numpy().astype(np.float64)       # A:248
+    iou = H.compute_IoU_whole_img_batch(pred, gt, thr)                           # A:252
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        iou_pc = torch.tensor(np.nanmean(iou, axis=0))                           # A:253
+    iou_pc[torch.isnan(iou_pc)] = 0                                              # A:254
+    store["agent/iou_per_instance"] = iou.numpy().copy()
+    store["agent/iou_per_class"] = iou_pc.numpy().copy()
+    store["agent/iou_nans"] = torch.sum(torch.isnan(iou), axis=0).numpy().copy()  # A:256
+    store["agent/acc_per_class"] = H.compute_accuracy(gt, pred, thr).numpy().copy()  # A:259
+    path = os.path.join(GOLD, "g6_frows.npz")
+    np.savez_compressed(path, **store)
+    print("G6 ->", os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, H = import_reference()
+    only = set(sys.argv[1:])   # e.g. `make_golden.py g6 g7` regenerates only those groups
+    if only:
+        for tag, fn in (("g1", g1_topology), ("g2", g2_tiny), ("g4", g4_c1), ("g3", g3_layers), ("g5", g5_trace), ("g6", g6_frows),
+                        ("g7", g7_configs)):
+            if tag in only:
+                fn(M, H)
+        return
     g1_topology(M, H)
     g2_tiny(M, H)
     g4_c1(M, H)
     g3_layers(M, H)
     g5_trace(M, H)
+    g6_frows(M, H)
+    g7_configs(M, H)
     leaked = [p for p, _, fs in os.walk(REF) if os.path.basename(p) == "__pycache__"]
     assert not leaked, f"bytecode leaked into the reference tree: {leaked}"
 

@@ -15,8 +15,12 @@ fp32) of the reference algorithm:
     M:85-92, M:97-98, M:169-176, M:180-181, M:186 and the key-remap regex M:281-282.
   * training step ..................... reference dmmfods/agents/Dense_U_Net_lidar_Agent.py:244-265
   * metrics ........................... reference dmmfods/utils/Dense_U_Net_lidar_helper.py:311-401
+  * focal losses ...................... reference dmmfods/graphs/losses/FocalLoss.py:41-50, 78-91
+  * batched-file slicing .............. reference dmmfods/datasets/WaymoData.py:87-103
+  * per-batch metric aggregation ...... reference dmmfods/agents/Dense_U_Net_lidar_Agent.py:252-260
 
-Parity pin: ``oracle/make_golden.py`` imports the reference's own ``Dense_U_Net_lidar`` class in
+Parity pin (G1-G5, G7 model; G6 focal losses / dataset slicing / agent metrics): ``oracle/make_golden.py`` imports the
+reference's own ``Dense_U_Net_lidar`` class (and ``FocalLoss``, ``WaymoDataset``, the helper's metric functions) in
 the build container (five absent third-party modules shimmed in memory), runs it on seeded
 inputs and commits the results under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks
 this restatement against those vectors.  The reference ships no golden vectors of its own.
@@ -389,6 +393,31 @@ def accuracy_per_class(gt: torch.Tensor, pred: torch.Tensor, thr: float = 0.7) -
     return eq / (gt.numel() / gt.shape[1])
 
 
+def focal_loss(x: torch.Tensor, t: torch.Tensor, alpha, gamma, logits: bool = True) -> torch.Tensor:
+    """Unreduced (class-wise) focal loss  alpha_c * (1 - exp(-bce))**gamma_c * bce  on (B, C, H, W) tensors (L:41-50; per class
+    L:78-91).  Scalars broadcast over the classes.  ``logits=False``: inputs are probabilities (L:43-44)."""
+    bce = bce_with_logits(x, t) if logits else F.binary_cross_entropy(x, t, reduction="none")
+    a = torch.as_tensor(alpha, dtype=x.dtype).reshape(1, -1, 1, 1)
+    g = torch.as_tensor(gamma, dtype=x.dtype).reshape(1, -1, 1, 1)
+    return a * (1.0 - torch.exp(-bce)) ** g * bce
+
+
+def split_batch(batch: torch.Tensor):
+    """(N, 7, H, W) batched file -> image (N,3,H,W), lidar (N,1,H,W), heat maps (N,3,H,W)   (D:87-103)."""
+    return batch[:, :3, :, :], batch[:, 3, :, :].unsqueeze(1), batch[:, 4:, :, :]
+
+
+def batch_metrics(logits: torch.Tensor, target: torch.Tensor, thr: float = 0.7):
+    """The agent's per-batch metric block (A:252-260): per-class IoU as the NaN-ignoring mean over samples with an all-NaN class
+    mapped to 0, the per-class NaN count, and the thresholded accuracy."""
+    iou = iou_whole_img_batch(logits, target, thr)
+    nan = torch.isnan(iou)
+    cnt = (~nan).sum(dim=0)
+    mean = torch.where(nan, torch.zeros_like(iou), iou).sum(dim=0) / cnt.clamp_min(1)
+    iou_pc = torch.where(cnt > 0, mean, torch.zeros_like(mean))
+    return iou_pc, nan.sum(dim=0), accuracy_per_class(target, logits, thr)
+
+
 def leaf_params(P: Dict[str, torch.Tensor], arch: Arch) -> List[Tuple[str, torch.Tensor]]:
     """Trainable tensors in ``nn.Module.parameters()`` order (the order Adam sees, A:57)."""
     return [(k, P[k]) for k, _, kind in param_table(arch) if kind in ("conv", "convT", "bn_w", "bn_b")]
@@ -399,8 +428,9 @@ class Trainer:
     zero_grad, backward(ones), Adam(lr 1e-3, betas .9/.999, eps 1e-8, wd 0, amsgrad False; H:146-159)."""
 
     def __init__(self, arch: Arch, P: Dict[str, torch.Tensor], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 iou_threshold: float = 0.7, storage=None):
+                 iou_threshold: float = 0.7, storage=None, loss_fn=None):
         self.arch, self.P, self.thr, self.storage = arch, P, iou_threshold, storage
+        self.loss_fn = loss_fn or bce_with_logits  # e.g. lambda x, t: focal_loss(x, t, alpha, gamma)
         self.leaves = leaf_params(P, arch)
         for _, t in self.leaves:
             t.requires_grad_(True)
@@ -409,7 +439,7 @@ class Trainer:
 
     def step(self, rgb, lidar, target, do_update: bool = True):
         logits = forward(self.P, self.arch, rgb, lidar, training=True, storage=self.storage)
-        loss = bce_with_logits(logits, target)
+        loss = self.loss_fn(logits, target)
         loss_per_class = loss.detach().sum(dim=(0, 2, 3))
         iou = iou_whole_img_batch(logits.detach(), target, self.thr)
         acc = accuracy_per_class(target, logits.detach(), self.thr)

@@ -1,0 +1,241 @@
+"""BASELINE configurations that round 1 left without a GPU parity test (C3 = DenseNet-121 mid-fusion, C5 architecture =
+DenseNet-201 mid-fusion), the fp16 training trajectory, shape fuzzing over H, W in 32*N and the call-order
+contracts of the model's backward entry points."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+VARIANTS = {"no": (1, 0), "early": (1, 3), "mid2": (2, 3), "mid3": (3, 3), "mid4": (4, 3)}
+TINY = dict(growth_rate=8, block_config=(2, 2, 2, 2), num_init_features=16)
+G3_ARCH = dict(growth_rate=24, block_config=(2, 2, 2, 2), num_init_features=48)
+
+
+def _arch(R, base, v):
+    cbb, s2 = VARIANTS[v]
+    return R.Arch(**base, concat_before_block_num=cbb, stream_2_in_channels=s2)
+
+
+def _model(arch, dtype="fp32", factory=None, **kw):
+    from dmmfods_amd.graphs.models import Dense_U_Net_lidar as M
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    cfg = get_config("/tmp/dmm_test")
+    cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = arch.growth_rate, arch.block_config, arch.num_init_features
+    cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = arch.concat_before_block_num, arch.stream_2_in_channels
+    if factory is not None:   # the reference's factories overwrite growth_rate / block_config / num_init_features (M:323-325)
+        return getattr(M, factory)(pretrained=False, config=cfg, compute_dtype=dtype, **kw)
+    return M.Dense_U_Net_lidar(cfg, compute_dtype=dtype, **kw)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _oracle_grads(R, arch, dt, B, H, W, seed, wseed, storage=None):
+    P = {k: (t.to(dt) if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=wseed).items()}
+    tr = R.Trainer(arch, P, storage=storage)
+    rgb, lidar, tgt = R.make_inputs(arch, B, H, W, seed=seed)
+    out = tr.step(rgb.to(dt), lidar.to(dt), tgt.to(dt), do_update=False)
+    return out, {k: t.grad.clone() for k, t in tr.leaves}
+
+
+@pytest.mark.parametrize("case", ["d121_mid3_64", "d121_mid3_128", "d201_mid3_64"])
+def test_baseline_architectures_against_reference_fixture(case, golden_dir):
+    """C3 (DenseNet-121, fusion before block 3) and the C5 architecture (DenseNet-201, fusion before block 3) built by the
+    factories, fp32: logits / loss sums / metrics / every parameter gradient against the fixture recorded from the reference's
+    own factories (tests/golden/g7_*.npz) and, at 64x96, noise-aware against the fp64 oracle."""
+    from oracle import restatement as R
+    g = np.load(os.path.join(golden_dir, f"g7_{case}.npz"))
+    meta = json.loads(bytes(g["meta/case"]).decode())
+    arch = _arch(R, R.DENSENETS[meta["densenet"]], meta["variant"])
+    model = _model(arch, factory=f"densenet{meta['densenet']}_u_lidar")
+    assert model.fusion == "mid" and model.num_params == R.num_params(arch)
+    model.load_state_dict(R.make_state(arch, seed=meta["weight_seed"]))
+    model = model.to(DEV).train()
+    B, H, W = meta["B"], meta["H"], meta["W"]
+    rgb, lidar, tgt = R.make_inputs(arch, B, H, W, seed=meta["data_seed"])
+    logits = model(rgb.to(DEV), lidar.to(DEV))
+    met = model.loss_backward(tgt.to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(logits.detach(), torch.from_numpy(g["logits_full"])) < 1e-3
+    np.testing.assert_allclose(met["loss_per_class"].cpu().double().numpy(), g["loss_per_class"], rtol=1e-4)
+    # thresholded counts: a logit within fp32 noise of the 0.7 threshold may fall on the other side (one pixel in 24 576 seen)
+    px = 3.0 / (H * W)
+    torch.testing.assert_close(met["iou_per_instance_per_class"].cpu(), torch.from_numpy(g["iou"]), rtol=1e-6, atol=20 * px, equal_nan=True)
+    torch.testing.assert_close(met["acc_per_class"].cpu(), torch.from_numpy(g["acc"]).float(), rtol=1e-6, atol=px)
+    # Gradients against the reference's own numbers.  Its fp32 CPU arithmetic is itself up to ~0.2 of a tensor's absmax away
+    # from an fp64 run on the cancelling BatchNorm-parameter sums of a 121/201-layer net, so: convolution weights
+    # per tensor at 3e-2 of absmax, BatchNorm parameters with a loose per-tensor backstop, and a global relative L2 over all
+    # sampled elements.
+    num = den = 0.0
+    for k, p in model.named_parameters():
+        mom, sample = g[f"grad/{k}/mom"], g[f"grad/{k}/sample"].astype(np.float64)
+        assert p.numel() == int(mom[0]), k
+        got = p.grad.detach().flatten()[:: int(mom[1])][: len(sample)].double().cpu().numpy()
+        err = np.abs(got - sample).max() / max(mom[4], 1e-30)
+        assert err < (3e-2 if p.dim() == 4 else 0.5), (k, err)
+        num += float(((got - sample) ** 2).sum())
+        den += float((sample ** 2).sum())
+    print(f"{case}: sampled-gradient rel L2 vs the reference fixture {(num / den) ** 0.5:.3e}")
+    assert (num / den) ** 0.5 < 2e-2
+    if H == 64:
+        _, g64 = _oracle_grads(R, arch, torch.float64, B, H, W, meta["data_seed"], meta["weight_seed"])
+        _, g32 = _oracle_grads(R, arch, torch.float32, B, H, W, meta["data_seed"], meta["weight_seed"])
+        num = den = num32 = 0.0
+        for k, p in model.named_parameters():
+            ref = g64[k]
+            num += float((p.grad.detach().cpu().double() - ref).pow(2).sum())
+            num32 += float((g32[k].double() - ref).pow(2).sum())
+            den += float(ref.pow(2).sum())
+        err, noise = (num / den) ** 0.5, (num32 / den) ** 0.5
+        print(f"{case}: global grad rel L2 gpu {err:.3e} cpu-fp32 {noise:.3e}")
+        assert err < max(2e-3, 3 * noise), (err, noise)
+
+
+def test_full_size_c2_batch4_step_properties():
+    """BASELINE configs[1] exactly (d121 early fusion, batch 4, 1280x1920, fp16 storage): size-independent properties.
+    (a) the fused loss equals BCE computed by torch on the returned logits; (b) metric counts equal torch's on those
+    logits; (c) every parameter tensor receives a finite, non-zero gradient; (d) a second identical step reproduces the loss."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, "fp16").to(DEV).train()
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    B = 4
+    rgb = torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) * 255
+    lidar = torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) * 255 * (torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) > 0.9)
+    tgt = (torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) > 0.9).float()
+    with torch.no_grad():
+        logits = model(rgb, lidar)
+    met = model.loss_backward(tgt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all()
+    ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt, reduction="none").double().sum(dim=(0, 2, 3))
+    assert _rel(met["loss_per_class"], ref_loss) < 1e-5
+    pred, gt = logits >= 0.7, tgt >= 0.7
+    inter, union = (pred & gt).sum(dim=(2, 3)).double(), (pred | gt).sum(dim=(2, 3)).double()
+    assert torch.equal(met["intersection"].cpu(), inter.cpu()) and torch.equal(met["union"].cpu(), union.cpu())
+    eq = (pred == gt).sum(dim=(0, 2, 3)).double() / float(B * 1280 * 1920)
+    torch.testing.assert_close(met["acc_per_class"].double().cpu(), eq.cpu(), rtol=1e-6, atol=1e-7)
+    ga = model.grad_arena
+    assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
+    nz = sum(1 for p in model.parameters() if float(p.grad.abs().max()) > 0)
+    assert nz == sum(1 for _ in model.parameters())          # every tensor received a gradient
+    loss1 = met["loss_per_class"].clone()
+    model._tracked_arena.zero_()
+    with torch.no_grad():
+        model(rgb, lidar)
+    met2 = model.loss_backward(tgt)
+    assert _rel(met2["loss_per_class"], loss1) < 1e-6
+
+
+def test_fp16_training_trajectory_tracks_fp32_oracle():
+    """Five optimiser steps of the timed configuration's arithmetic (fp16 storage, fp32 accumulate) on the K = 48/72/96 net:
+    the per-step loss sums stay within a stated bound of the fp32 CPU oracle's trajectory, and the first step's gradients are
+    within a norm-wise bound of the oracle's fp16-storage emulation."""
+    from oracle import restatement as R
+    from dmmfods_amd.optim import FusedAdam
+    arch = _arch(R, G3_ARCH, "mid3")
+    P = R.make_state(arch, seed=321)
+    tr = R.Trainer(arch, P)
+    model = _model(arch, "fp16")
+    model.load_state_dict(R.make_state(arch, seed=321))
+    model = model.to(DEV).train()
+    opt = FusedAdam(model)
+    # first-step gradients against the fp16-storage emulation of the oracle (fp64 arithmetic)
+    _, gh = _oracle_grads(R, arch, torch.float64, 2, 64, 96, 0, 321, storage=torch.float16)
+    devs = []
+    for step in range(5):
+        rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=step)
+        ref = tr.step(rgb, lidar, tgt)
+        with torch.no_grad():
+            model(rgb.to(DEV), lidar.to(DEV))
+        met = model.loss_backward(tgt.to(DEV))
+        if step == 0:
+            num = den = 0.0
+            for k, p in model.named_parameters():
+                num += (p.grad.detach().cpu().double() - gh[k]).pow(2).sum().item()
+                den += gh[k].pow(2).sum().item()
+            g_err = (num / den) ** 0.5
+        opt.step()
+        got = met["loss_per_class"].double().cpu()
+        want = ref["loss_per_class"].double()
+        devs.append(((got - want).abs() / want.abs()).max().item())
+    torch.cuda.synchronize()
+    print("fp16 trajectory: per-step max rel loss deviation", ["%.2e" % d for d in devs], "step-0 grad rel L2 vs fp16 emulation %.3e" % g_err)
+    assert max(devs) < 1e-2, devs          # measured 1e-4 .. 2e-3
+    assert g_err < 0.08, g_err             # measured ~3e-2
+
+
+@pytest.mark.parametrize("variant,H,W", [("early", 32, 32), ("mid3", 32, 96), ("no", 96, 32), ("mid2", 160, 64), ("mid4", 224, 96),
+                                         ("early", 96, 352)])
+def test_shape_fuzz_multiples_of_32(variant, H, W):
+    """sizes H, W in 32*N that are neither square nor powers of two (row tiles straddle image rows and batch
+    borders; 1x1 ... 7x11 maps in block 4): logits, loss, and all gradients of the tiny net against the fp64 oracle."""
+    from oracle import restatement as R
+    arch = _arch(R, TINY, variant)
+    B = 3
+    o64, g64 = _oracle_grads(R, arch, torch.float64, B, H, W, seed=H + W, wseed=5)
+    _, g32 = _oracle_grads(R, arch, torch.float32, B, H, W, seed=H + W, wseed=5)
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=5))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, B, H, W, seed=H + W)
+    logits = model(rgb.to(DEV), lidar.to(DEV))
+    met = model.loss_backward(tgt.to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(logits.detach(), o64["logits"]) < 1e-3
+    assert _rel(met["loss_per_class"], o64["loss_per_class"]) < 1e-5
+    for k, p in model.named_parameters():
+        ref = g64[k]
+        s = ref.abs().max().clamp_min(1e-30)
+        err = ((p.grad.detach().cpu().double() - ref).abs().max() / s).item()
+        noise = ((g32[k].double() - ref).abs().max() / s).item()
+        assert err < max(3e-3, 4 * noise), (k, err, noise)
+    with pytest.raises(ValueError):       # reference: ValueError from ConvTranspose2d(output_size=...) (M:261)
+        model(torch.zeros(1, 3, H + 8, W, device=DEV), torch.zeros(1, max(arch.stream_2_in_channels, 1), H + 8, W, device=DEV))
+
+
+def test_autograd_backward_after_fused_backward_does_not_accumulate():
+    """dmm_plan_backward (the autograd bridge) must clear the gradient arena like the fused tail does: refine0's weight
+    gradient is ADDED into the arena by the four output-parity phases, so a stale arena would leak into the result."""
+    from oracle import restatement as R
+    arch = _arch(R, TINY, "mid3")
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=123))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, 2, 64, 96, seed=0)
+    rgb, lidar, tgt = rgb.to(DEV), lidar.to(DEV), tgt.to(DEV)
+    with torch.no_grad():
+        model(rgb, lidar)
+    model.loss_backward(tgt)
+    want = model.grad_arena.clone()
+    k = "dec_out_to_heat_maps.refine0.weight"
+    want_r0 = dict(model.named_parameters())[k].grad.clone()
+    for _ in range(2):                      # twice in a row: an accumulating path would keep growing
+        pred = model(rgb, lidar)
+        loss = torch.nn.BCEWithLogitsLoss(reduction="none")(pred, tgt)
+        loss.backward(torch.ones_like(loss))
+        torch.cuda.synchronize()
+        assert _rel(dict(model.named_parameters())[k].grad, want_r0) < 1e-5
+        assert ((model.grad_arena - want).norm() / want.norm()).item() < 1e-5
+
+
+def test_loss_backward_requires_training_forward():
+    from oracle import restatement as R
+    arch = _arch(R, TINY, "no")
+    model = _model(arch).to(DEV)
+    rgb, lidar, tgt = R.make_inputs(arch, 1, 32, 32, seed=0)
+    model.train()
+    with torch.no_grad():
+        model(rgb.to(DEV), None)
+    model.loss_backward(tgt.to(DEV))              # fine
+    model.eval()
+    with torch.no_grad():
+        model(rgb.to(DEV), None)
+    with pytest.raises(RuntimeError):             # an eval forward leaves no batch statistics / saved activations to backprop through
+        model.loss_backward(tgt.to(DEV))

@@ -1,0 +1,118 @@
+"""Data parallelism at model level: two replicas with per-replica BatchNorm statistics and SUMMED gradients
+against the oracle run the same way, and the bucketed exchange over RCCL on the real gradient arena (single rank: the
+collectives are issued for real, the values must not change)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G3_ARCH = dict(growth_rate=24, block_config=(2, 2, 2, 2), num_init_features=48)
+
+
+def _model(arch, dtype="fp32"):
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
+    cfg = get_config("/tmp/dmm_test")
+    cfg.model.growth_rate, cfg.model.block_config, cfg.model.num_init_features = arch.growth_rate, arch.block_config, arch.num_init_features
+    cfg.model.concat_before_block_num, cfg.model.stream_2_in_channels = arch.concat_before_block_num, arch.stream_2_in_channels
+    return Dense_U_Net_lidar(cfg, compute_dtype=dtype)
+
+
+def test_two_replicas_sum_convention_matches_oracle():
+    """Global batch 4 as two replicas of 2: each replica normalises with ITS OWN batch statistics, the exchanged gradient is the
+    SUM of the replicas' gradients (the reference loss is an un-normalised sum over pixels, A:264).  The oracle does exactly
+    that on the CPU in fp64; the single-process batch-4 gradient differs (shared statistics), which the test also shows."""
+    from oracle import restatement as R
+    arch = R.Arch(**G3_ARCH, concat_before_block_num=3, stream_2_in_channels=3)
+    rgb, lidar, tgt = R.make_inputs(arch, 4, 64, 96, seed=21)
+    # oracle: two half-batch steps on identical weights, gradients summed
+    want, want32 = {}, {}
+    for dt, acc in ((torch.float64, want), (torch.float32, want32)):
+        for half in (slice(0, 2), slice(2, 4)):
+            P = {k: (t.to(dt) if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=9).items()}
+            tr = R.Trainer(arch, P)
+            tr.step(rgb[half].to(dt), lidar[half].to(dt), tgt[half].to(dt), do_update=False)
+            for k, t in tr.leaves:
+                acc[k] = acc.get(k, 0) + t.grad.double()
+    P = {k: (t.double() if t.is_floating_point() else t.clone()) for k, t in R.make_state(arch, seed=9).items()}
+    tr = R.Trainer(arch, P)
+    tr.step(rgb.double(), lidar.double(), tgt.double(), do_update=False)
+    full = {k: t.grad.clone() for k, t in tr.leaves}
+    # HIP: the two replicas one after the other on this GPU, arenas summed as the all-reduce would
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=9))
+    model = model.to(DEV).train()
+    total = torch.zeros_like(model.grad_arena)
+    for half in (slice(0, 2), slice(2, 4)):
+        with torch.no_grad():
+            model(rgb[half].to(DEV), lidar[half].to(DEV))
+        model.loss_backward(tgt[half].to(DEV))
+        total += model.grad_arena
+    torch.cuda.synchronize()
+    num = den = num32 = dfull = 0.0
+    off = 0
+    for k, p in model.named_parameters():
+        n = p.numel()
+        got = total[off:off + n].view(p.shape).cpu().double()
+        off += n
+        num += float((got - want[k]).pow(2).sum())
+        num32 += float((want32[k] - want[k]).pow(2).sum())
+        dfull += float((full[k] - want[k]).pow(2).sum())
+        den += float(want[k].pow(2).sum())
+    err, noise, sep = (num / den) ** 0.5, (num32 / den) ** 0.5, (dfull / den) ** 0.5
+    print(f"DP sum-of-replicas: rel L2 gpu {err:.3e}, cpu-fp32 {noise:.3e}; single-process batch-4 differs by {sep:.3e}")
+    assert err < max(2e-3, 3 * noise), (err, noise)
+    assert sep > 10 * err          # per-replica BatchNorm is a different function from batch-4 BatchNorm: the test can tell them apart
+
+
+def test_bucketed_allreduce_over_rccl_keeps_single_rank_gradients():
+    """World size 1 with the collectives FORCED: every plan bucket goes through an RCCL all-reduce enqueued behind its
+    readiness event while backward is still running; a SUM over one rank must return the gradients bit for bit, and the
+    buckets must arrive complete (compared with a backward that exchanged nothing)."""
+    import torch.distributed as dist
+    from oracle import restatement as R
+    from dmmfods_amd import _lib
+    from dmmfods_amd.parallel import GradAllReduce, broadcast_parameters
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        _lib.check(_lib.lib().dmm_set_option(b"grad_bucket_mb", 1))     # several buckets even on a small net
+        arch = R.Arch(growth_rate=32, block_config=(2, 2, 2, 2), num_init_features=64, concat_before_block_num=3, stream_2_in_channels=3)
+        model = _model(arch, "fp16")
+        model.load_state_dict(R.make_state(arch, seed=4))
+        model = model.to(DEV).train()
+        rgb, lidar, tgt = R.make_inputs(arch, 2, 128, 192, seed=2)
+        rgb, lidar, tgt = rgb.to(DEV), lidar.to(DEV), tgt.to(DEV)
+        with torch.no_grad():
+            model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        plain = model.grad_arena.clone()
+        buckets = model.grad_buckets()
+        assert len(buckets) >= 3 and sum(c for _, c in buckets) == model.grad_arena.numel()
+        red = GradAllReduce(model, force=True)
+        broadcast_parameters(model, force=True)
+        for _ in range(3):
+            with torch.no_grad():
+                model(rgb, lidar)
+            model.loss_backward(tgt)
+            works = red.reduce_overlapped()
+            assert len(works) == len(buckets)
+            GradAllReduce.wait(works)
+            torch.cuda.synchronize()
+            assert ((model.grad_arena - plain).norm() / plain.norm()).item() < 1e-5     # fp32 atomics order only
+        # the non-overlapped exchange over the same arena
+        works = red.all_reduce(async_op=True)
+        GradAllReduce.wait(works)
+        torch.cuda.synchronize()
+        assert ((model.grad_arena - plain).norm() / plain.norm()).item() < 1e-5
+    finally:
+        _lib.check(_lib.lib().dmm_set_option(b"grad_bucket_mb", 25))
+        if created:
+            dist.destroy_process_group()

@@ -127,27 +127,104 @@ def test_config_fields_match_reference():
     assert set(create_config("/tmp/x")) == {"dir", "scripts", "model", "loss", "loader", "optimizer", "dataset", "agent"}
 
 
+def _plan_buckets(lib, cbb, s2, bc=(6, 12, 24, 16)):
+    L = lib.lib()
+    d = lib.ModelDesc(growth_rate=32, num_blocks=4, num_init_features=64, bn_size=4, num_classes=3, concat_before_block_num=cbb,
+                      stream_1_in_channels=3, stream_2_in_channels=s2, batch=1, height=64, width=96, dtype=1, loss_scale=1.0,
+                      bn_momentum=0.1, bn_eps=1e-5, iou_threshold=0.7, use_mfma=1)
+    for i, v in enumerate(bc):
+        d.block_config[i] = v
+    h = C.c_void_p()
+    lib.check(L.dmm_plan_create(C.byref(d), C.byref(h)))
+    out = []
+    for i in range(L.dmm_plan_num_grad_buckets(h)):
+        o, c = C.c_int64(), C.c_int64()
+        lib.check(L.dmm_plan_grad_bucket(h, i, C.byref(o), C.byref(c)))
+        out.append((o.value, c.value))
+    n = L.dmm_plan_num_params(h)
+    table = []
+    for i in range(L.dmm_plan_num_tensors(h)):
+        name, kind, nd = C.c_char_p(), C.c_int32(), C.c_int32()
+        shape, off = (C.c_int64 * 4)(), C.c_int64()
+        lib.check(L.dmm_plan_tensor_info(h, i, C.byref(name), C.byref(kind), C.byref(nd), C.byref(shape), C.byref(off)))
+        table.append((name.value.decode(), kind.value, off.value))
+    L.dmm_plan_destroy(h)
+    return out, n, table
+
+
+def test_grad_buckets_cover_arena_in_backward_order(lib):
+    """The plan's data-parallel buckets: whole tensors, an exact partition of the gradient arena, listed in the order backward
+    finishes them (decoder/head before block 4 ... before the stems; the second stream of a mid-fusion net last)."""
+    for cbb, s2 in ((1, 3), (3, 3)):
+        buckets, n, table = _plan_buckets(lib, cbb, s2)
+        assert len(buckets) >= 3
+        spans = sorted(buckets)
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+            assert o0 + c0 == o1                                   # no gap, no overlap
+        starts = {off for _, kind, off in table if kind <= lib.T_BN_BIAS}
+        assert all(o in starts for o, _ in buckets)                # buckets begin at tensor boundaries
+        where = {name: off for name, kind, off in table if kind <= lib.T_BN_BIAS}
+
+        def pos(name):
+            off = where[name]
+            return next(i for i, (o, c) in enumerate(buckets) if o <= off < o + c)
+        assert pos("decoder.Transposed_Convolution_4.weight") <= pos("features.denseblock4.denselayer16.conv2.weight")
+        assert pos("features.denseblock4.denselayer16.conv2.weight") <= pos("features.denseblock1.denselayer1.conv1.weight")
+        assert pos("features.conv0.weight") >= pos("features.denseblock3.denselayer1.conv1.weight")
+        if cbb == 3:
+            assert pos("stream_2_features.conv0.weight") == len(buckets) - 1
+
+
 _DP_SCRIPT = r"""
-import os, sys, torch, torch.distributed as dist
+import json, os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from dmmfods_amd.parallel import GradAllReduce
+from dmmfods_amd.parallel import GradAllReduce, broadcast_parameters
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
-r = GradAllReduce(arena, bucket_bytes=1024)   # 256-element buckets -> 4 collectives
-r.all_reduce()
-want = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
-assert torch.equal(arena, want), (rank, arena[:5])
+buckets, n = json.loads(os.environ["DMM_BUCKETS"]), int(os.environ["DMM_NPARAMS"])
+
+class FakeModel:            # the surface GradAllReduce uses: grad_arena, grad_buckets(), param_arena / _buffer_arena
+    def __init__(self):
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.grad_arena = torch.randn(n, generator=g)
+        self.param_arena = torch.full((n,), float(rank))
+        self._buffer_arena = torch.full((17,), float(rank))
+    def grad_buckets(self):
+        return [tuple(b) for b in buckets]
+
+m = FakeModel()
+mine = m.grad_arena.clone()
+r = GradAllReduce(m)
+works = r.reduce_overlapped()                      # one collective per plan bucket, in readiness order
+assert len(works) == len(buckets) and r.last_ranges == [tuple(b) for b in buckets]
+GradAllReduce.wait(works)
+other = torch.randn(n, generator=torch.Generator().manual_seed(1234 + (1 - rank)))
+assert torch.equal(m.grad_arena, mine + other) or torch.equal(m.grad_arena, other + mine), rank     # SUM, every element once
+broadcast_parameters(m, src=0)
+assert float(m.param_arena.max()) == 0.0 and float(m._buffer_arena.max()) == 0.0
+# the plain post-backward exchange with a bucket size that does not divide the arena
+a2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+r2 = GradAllReduce(a2, bucket_bytes=(7 << 20) + 12)
+r2.all_reduce()
+assert r2.last_ranges[-1][0] + r2.last_ranges[-1][1] == n and r2.last_ranges[-1][1] != r2.last_ranges[0][1]
+assert torch.equal(a2, torch.arange(n, dtype=torch.float32) * 3)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 
 
-def test_grad_allreduce_sum_gloo_world2(tmp_path):
+def test_grad_allreduce_real_size_arena_gloo_world2(lib, tmp_path):
+    """World-size-2 exchange over an arena of the C3 model's real size (23.6 M elements) cut into the plan's own buckets:
+    coverage, order, SUM convention and the parameter broadcast."""
+    import json
+    buckets, n, _ = _plan_buckets(lib, 3, 3)
+    assert n == 23567564
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2", DMM_BUCKETS=json.dumps(buckets),
+               DMM_NPARAMS=str(n))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs

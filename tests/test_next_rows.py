@@ -53,21 +53,84 @@ def test_dataset_reads_reference_batched_format(tmp_path):
         WaymoDataset("bogus", cfg)
 
 
-def test_focal_losses_match_definition():
+def test_dataset_matches_reference_get_batch(tmp_path, golden_dir):
+    """The batch files of fixture G6 read through WaymoDataset / WaymoDataset_Loader: the slices equal what the reference's
+    WaymoDataset.get_batch (D:87-103) returned for the same files, and the loader bookkeeping equals D:160-213."""
+    import json
+    import numpy as np
+    from dmmfods_amd.datasets.WaymoData import WaymoDataset, WaymoDataset_Loader
+    g = np.load(os.path.join(golden_dir, "g6_frows.npz"))
+    cfg = _cfg(tmp_path)
+    for mode in ("train", "val"):
+        d = os.path.join(cfg.dir.data.root, mode, "part0")
+        os.makedirs(os.path.join(d, "labels"), exist_ok=True)
+        for i in range(2):
+            torch.save(torch.from_numpy(g[f"data/{mode}/batch_{i}"]), os.path.join(d, f"batch_{i}.pt"))
+    ds = WaymoDataset("train", cfg)
+    assert len(ds) == int(g["data/len"])
+    assert sorted(ds.files) == json.loads(bytes(g["data/train_files"]).decode())
+    for i, f in enumerate(sorted(ds.files)):
+        img, lid, hm = ds[ds.files.index(f)]
+        assert np.array_equal(img.numpy(), g[f"data/get_batch/{i}/image"])
+        assert np.array_equal(lid.numpy(), g[f"data/get_batch/{i}/lidar"])
+        assert np.array_equal(hm.numpy(), g[f"data/get_batch/{i}/ht_map"])
+    ld = WaymoDataset_Loader(cfg)
+    assert [ld.train_iterations, ld.valid_iterations] == list(g["data/iterations"])
+    first = next(iter(ld.valid_loader))
+    assert [list(v.shape) for v in first] == g["data/loader_first_val_shapes"].tolist()
+
+
+def test_agent_batch_metrics_match_reference_block(golden_dir):
+    """Dense_U_Net_lidar_Agent._batch_metrics (device-side, no host sync) on the IoU table of fixture G6 against the reference's
+    np.nanmean / NaN-to-0 / NaN-count block (A:252-256)."""
+    import numpy as np
+    from dmmfods_amd.agents.Dense_U_Net_lidar_Agent import Dense_U_Net_lidar_Agent
+    from dmmfods_amd.utils import Dense_U_Net_lidar_helper as U
+    g = np.load(os.path.join(golden_dir, "g6_frows.npz"))
+    pred, gt = torch.from_numpy(g["agent/pred"]), torch.from_numpy(g["agent/gt"])
+    iou = U.compute_IoU_whole_img_batch(pred, gt, 0.7)
+    np.testing.assert_allclose(iou.numpy(), g["agent/iou_per_instance"], rtol=1e-6, equal_nan=True)
+    m = {"iou_per_instance_per_class": iou, "acc_per_class": U.compute_accuracy(gt, pred, 0.7)}
+    iou_pc, nans, acc = Dense_U_Net_lidar_Agent._batch_metrics(m)
+    np.testing.assert_allclose(iou_pc.numpy(), g["agent/iou_per_class"], rtol=1e-6)
+    assert np.array_equal(nans.numpy(), g["agent/iou_nans"])
+    np.testing.assert_allclose(acc.numpy(), g["agent/acc_per_class"], rtol=1e-6)
+
+
+def test_focal_loss_surface():
     from dmmfods_amd.graphs.losses.FocalLoss import ClassWiseFocalLoss, FocalLoss
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, 3, 5, 7, generator=g)
-    t = (torch.rand(2, 3, 5, 7, generator=g) > 0.8).float()
-    bce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
-    want = 0.5 * (1 - torch.exp(-bce)) ** 2 * bce
-    torch.testing.assert_close(FocalLoss(alpha=0.5, gamma=2, logits=True, reduce=False)(x, t), want)
-    torch.testing.assert_close(FocalLoss(alpha=0.5, gamma=2, logits=True, reduce=True)(x, t), want.mean())
-    alpha, gamma = [1.0, 2.0, 0.5], [2.0, 1.0, 3.0]
-    cw = ClassWiseFocalLoss(alpha, gamma)(x, t)
-    for c in range(3):
-        torch.testing.assert_close(cw[:, c], alpha[c] * (1 - torch.exp(-bce[:, c])) ** gamma[c] * bce[:, c])
-    p = torch.sigmoid(x)
-    torch.testing.assert_close(FocalLoss(1, 2, logits=False, reduce=False)(p, t), (1 - torch.exp(-bce)) ** 2 * bce, rtol=1e-4, atol=1e-5)
+    f = FocalLoss()
+    assert (f.alpha, f.gamma, f.logits, f.reduce) == (1, 2, False, True)          # reference defaults L:15
+    c = ClassWiseFocalLoss()
+    assert (c.alpha, c.gamma, c.logits, c.reduce) == ([1, 1, 1], [2, 2, 2], True, False)   # L:60
+    with pytest.raises(RuntimeError, match="GPU only"):   # no CPU fallback
+        c(torch.zeros(1, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+    with pytest.raises(ValueError):
+        ClassWiseFocalLoss([1, 2], [1, 2, 3])
+
+
+@pytest.mark.gpu
+def test_focal_kernel_matches_reference_fixture(golden_dir):
+    """The HIP loss epilogue (dmm_loss_forward) against the outputs and input gradients the reference's FocalLoss /
+    ClassWiseFocalLoss produced on the same tensors (fixture G6)."""
+    import numpy as np
+    from dmmfods_amd.graphs.losses.FocalLoss import ClassWiseFocalLoss, FocalLoss
+    g = np.load(os.path.join(golden_dir, "g6_frows.npz"))
+    x, t = torch.from_numpy(g["focal/x"]).cuda(), torch.from_numpy(g["focal/t"]).cuda()
+    cases = {"focal_a1_g2": FocalLoss(alpha=1, gamma=2, logits=True, reduce=False),
+             "focal_a025_g15": FocalLoss(alpha=0.25, gamma=1.5, logits=True, reduce=False),
+             "classwise_default": ClassWiseFocalLoss(),
+             "classwise_mixed": ClassWiseFocalLoss(alpha=[1.0, 2.0, 0.5], gamma=[2.0, 1.0, 3.0])}
+    for name, fn in cases.items():
+        xi = x.clone().requires_grad_(True)
+        out = fn(xi, t)
+        out.backward(torch.ones_like(out))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"focal/{name}/loss"], rtol=2e-5, atol=2e-7)
+        np.testing.assert_allclose(xi.grad.cpu().numpy(), g[f"focal/{name}/dx"], rtol=2e-4, atol=2e-6)
+    mean = FocalLoss(alpha=1, gamma=2, logits=True, reduce=True)(x, t)
+    np.testing.assert_allclose(mean.item(), float(g["focal/focal_a1_g2/mean"]), rtol=1e-5)
+    prob = FocalLoss(alpha=1, gamma=2, logits=False, reduce=False)(torch.sigmoid(x), t)
+    np.testing.assert_allclose(prob.cpu().numpy(), g["focal/prob_a1_g2/loss"], rtol=2e-4, atol=2e-6)
 
 
 def test_agent_module_surface():
@@ -118,10 +181,17 @@ def test_agent_trains_validates_and_resumes(tmp_path):
     torch.testing.assert_close(agent2.model.param_arena.cpu(), agent.model.param_arena.cpu())
     assert agent2.optimizer.step_count == 4
     torch.testing.assert_close(agent2.optimizer.exp_avg.cpu(), agent.optimizer.exp_avg.cpu())
-    # focal loss through the autograd bridge (reference L:52-91 as an alternative loss)
+    # class-wise focal loss (reference L:52-91) as the loss epilogue of the fused tail == the same loss through the autograd bridge
     from dmmfods_amd.graphs.losses.FocalLoss import ClassWiseFocalLoss
     image, lidar, ht = next(iter(agent.data_loader.train_loader))
-    agent.model.train()
-    pred = agent.model(image.cuda(), lidar.cuda())
-    ClassWiseFocalLoss()(pred, ht.cuda()).sum().backward()
-    assert torch.isfinite(agent.model.grad_arena).all() and float(agent.model.grad_arena.abs().max()) > 0
+    loss = ClassWiseFocalLoss(alpha=[1.0, 2.0, 0.5], gamma=[2.0, 1.0, 3.0])
+    agent3 = Dense_U_Net_lidar_Agent(cfg, loss=loss)
+    m = agent3.model.train()
+    pred = m(image.cuda(), lidar.cuda())
+    unreduced = loss(pred, ht.cuda())
+    unreduced.backward(torch.ones_like(unreduced))
+    g_auto = m.grad_arena.clone()
+    met = m.loss_backward(ht.cuda())
+    torch.testing.assert_close(met["loss_per_class"].double(), unreduced.detach().double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+    assert torch.isfinite(g_auto).all() and float(g_auto.abs().max()) > 0
+    assert ((m.grad_arena - g_auto).norm() / g_auto.norm()).item() < 1e-5

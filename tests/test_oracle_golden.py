@@ -207,3 +207,56 @@ def test_g5_flop_trace_matches_restatement(golden_dir):
         assert abs(fl - ent["fwd_gflop_per_img"]) < 1e-6 * ent["fwd_gflop_per_img"] + 1e-6, (cname, fl, ent["fwd_gflop_per_img"])
         assert abs(ent["fwd_gflop_per_img"] - want[cname]) < 0.06, cname
         assert len(ent["convs"]) == sum(1 for _, _, kind in R.param_table(arch) if kind in ("conv", "convT")), cname
+
+
+@pytest.mark.parametrize("case", ["d121_mid3_64", "d201_mid3_64"])
+def test_g7_baseline_architectures(golden_dir, case):
+    """The C3 (DenseNet-121 mid-fusion) and C5 (DenseNet-201 mid-fusion) architectures as built by the reference's factories
+    (M:335-347, M:377-388): logits, loss sums, metrics and every parameter gradient of one training step."""
+    g = np.load(os.path.join(golden_dir, f"g7_{case}.npz"))
+    meta = json.loads(bytes(g["meta/case"]).decode())
+    arch = _arch(R.DENSENETS[meta["densenet"]], meta["variant"])
+    P = R.make_state(arch, seed=meta["weight_seed"])
+    tr = R.Trainer(arch, P)
+    rgb, lidar, tgt = R.make_inputs(arch, meta["B"], meta["H"], meta["W"], seed=meta["data_seed"])
+    out = tr.step(rgb, lidar, tgt, do_update=False)
+    ref = g["logits_full"]
+    np.testing.assert_allclose(out["logits"].numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(out["loss_per_class"].double().numpy(), g["loss_per_class"], rtol=1e-5)
+    np.testing.assert_allclose(out["iou"].numpy(), g["iou"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(out["acc"].numpy(), g["acc"], rtol=1e-6)
+    for k, t in tr.leaves:
+        _check_digest(g, f"grad/{k}", t.grad, rtol=5e-3)   # fp32 summation-order noise of cancelling BatchNorm sums
+
+
+def test_g6_focal_dataset_and_agent_metrics(golden_dir, tmp_path):
+    """Rows 8(f): the oracle's focal losses, batched-file slicing and per-batch metric aggregation against what the reference's
+    FocalLoss / ClassWiseFocalLoss (L:9-91), WaymoDataset.get_batch (D:87-103) and agent block (A:247-260) produced."""
+    g = np.load(os.path.join(golden_dir, "g6_frows.npz"))
+    x, t = torch.from_numpy(g["focal/x"]), torch.from_numpy(g["focal/t"])
+    cases = {"focal_a1_g2": (1.0, 2.0), "focal_a025_g15": (0.25, 1.5), "classwise_default": ([1, 1, 1], [2, 2, 2]),
+             "classwise_mixed": ([1.0, 2.0, 0.5], [2.0, 1.0, 3.0])}
+    for name, (al, ga) in cases.items():
+        xi = x.clone().requires_grad_(True)
+        out = R.focal_loss(xi, t, al, ga)
+        out.sum().backward()
+        np.testing.assert_allclose(out.detach().numpy(), g[f"focal/{name}/loss"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(xi.grad.numpy(), g[f"focal/{name}/dx"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(R.focal_loss(x, t, 1.0, 2.0).mean().item(), float(g["focal/focal_a1_g2/mean"]), rtol=1e-5)
+    np.testing.assert_allclose(R.focal_loss(torch.sigmoid(x), t, 1.0, 2.0, logits=False).numpy(), g["focal/prob_a1_g2/loss"],
+                               rtol=1e-5, atol=1e-7)
+    for i in range(int(g["data/len"])):
+        img, lid, hm = R.split_batch(torch.from_numpy(g[f"data/train/batch_{i}"]))
+        files = json.loads(bytes(g["data/train_files"]).decode())
+        assert files[i].endswith(f"batch_{i}.pt")
+        assert np.array_equal(img.numpy(), g[f"data/get_batch/{i}/image"])
+        assert np.array_equal(lid.numpy(), g[f"data/get_batch/{i}/lidar"])
+        assert np.array_equal(hm.numpy(), g[f"data/get_batch/{i}/ht_map"])
+    pred, gt = torch.from_numpy(g["agent/pred"]), torch.from_numpy(g["agent/gt"])
+    np.testing.assert_allclose(R.bce_with_logits(pred, gt).double().sum(dim=(0, 2, 3)).numpy(), g["agent/loss_per_class"], rtol=1e-6)
+    np.testing.assert_allclose(R.iou_whole_img_batch(pred, gt).numpy(), g["agent/iou_per_instance"], rtol=1e-6, equal_nan=True)
+    iou_pc, nans, acc = R.batch_metrics(pred, gt)
+    np.testing.assert_allclose(iou_pc.numpy(), g["agent/iou_per_class"], rtol=1e-6)
+    assert np.array_equal(nans.numpy(), g["agent/iou_nans"])
+    np.testing.assert_allclose(acc.numpy(), g["agent/acc_per_class"], rtol=1e-6)
+    assert int(nans.sum()) >= 5 and float(iou_pc[1]) == 0.0    # the fixture does exercise the NaN rules
