@@ -28,9 +28,10 @@ CONFIGS = {
     "c2": dict(depth=121, cbb=1, s2=3, batch=4, H=1280, W=1920, dtype="fp16", name="C2 d121 early-fusion 6ch b4 1280x1920"),
     "c3": dict(depth=121, cbb=3, s2=3, batch=4, H=1280, W=1920, dtype="fp16", name="C3 d121 mid-fusion(3) b4/GPU 1280x1920"),
     "c4": dict(depth=169, cbb=3, s2=3, batch=2, H=1280, W=1920, dtype="fp16", name="C4 d169 mid-fusion(3) b2/GPU 1280x1920"),
-    "c5": dict(depth=201, cbb=3, s2=3, batch=8, H=640, W=960, dtype="fp16", name="C5 d201 mid-fusion(3) b8/GPU 640x960"),
+    "c5": dict(depth=201, cbb=3, s2=3, batch=8, H=640, W=960, dtype="bf16", name="C5 d201 mid-fusion(3) b8/GPU 640x960 mixed bf16"),
 }
-PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+DTYPE_LABEL = {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}
 EVENT_PASSES = 3
 PEAK_HBM_GBS = 8000.0
 
@@ -190,7 +191,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default=None, choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -288,7 +289,7 @@ def main():
         roof, table = (None, None)
         if not args.no_profile and full_classes:
             timed = collect_profile(model, plan, args.steps)
-            roof, table = roofline_block(full_classes, c["dtype"], (args.config, c["batch"], "f16" if c["dtype"] in ("fp16", "f16", "float16") else "f32"), timed)
+            roof, table = roofline_block(full_classes, c["dtype"], (args.config, c["batch"], DTYPE_LABEL[c["dtype"]]), timed)
             if ops_list:
                 ops_list.sort(reverse=True)
                 for ms_, lab, fl, by in ops_list[:args.ops]:
@@ -298,7 +299,7 @@ def main():
             "metric": metric_label(c),
             "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if c["dtype"] == "fp16" else "f32", "data": "synthetic",
+            "dtype": DTYPE_LABEL[c["dtype"]], "data": "synthetic",
             "config": {"workload": c["name"], "per_gpu_batch": c["batch"], "global_batch": c["batch"] * world,
                        "height": c["H"], "width": c["W"], "storage_dtype": c["dtype"], "accumulate": "fp32",
                        "parallelism": f"dp{world}", "weights": "random-init (reference init, seed 123)",

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMM_LIB_PATH") or os.path.join(_HERE, "libdmmfods_hip.so")  # DMM_LIB_PATH: experiment builds
 
-DMM_F32, DMM_F16 = 0, 1
+DMM_F32, DMM_F16, DMM_BF16 = 0, 1, 2
 LOSS_BCE, LOSS_FOCAL = 0, 1
 T_CONV, T_CONVT, T_BN_WEIGHT, T_BN_BIAS, T_BN_MEAN, T_BN_VAR, T_BN_TRACKED = range(7)
 ERR_INVALID, ERR_SHAPE, ERR_HIP, ERR_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5

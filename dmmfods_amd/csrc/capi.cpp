@@ -48,7 +48,9 @@ int dmm_set_option(const char* name, int value) {
 int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   if (!desc || !out) return fail(DMM_ERR_INVALID, "null argument");
   if (desc->num_blocks < 2 || desc->num_blocks > 8) return fail(DMM_ERR_INVALID, "num_blocks must be in [2, 8]");
-  if (desc->dtype != DMM_F32 && desc->dtype != DMM_F16) return fail(DMM_ERR_INVALID, "dtype must be DMM_F32 or DMM_F16");
+  if (desc->dtype != DMM_F32 && desc->dtype != DMM_F16 && desc->dtype != DMM_BF16)
+    return fail(DMM_ERR_INVALID, "dtype must be DMM_F32, DMM_F16 or DMM_BF16");
+  if (desc->dtype == DMM_BF16 && !desc->use_mfma) return fail(DMM_ERR_INVALID, "DMM_BF16 has no scalar check kernels: use_mfma must be 1");
   if (desc->batch < 1) return fail(DMM_ERR_INVALID, "batch must be >= 1");
   if (!(desc->loss_scale > 0)) return fail(DMM_ERR_INVALID, "loss_scale must be > 0");
   dmm_plan* p = new dmm_plan();

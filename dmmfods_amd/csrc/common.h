@@ -11,11 +11,15 @@ namespace dmm {
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16;  // storage/MFMA type of the "mixed bf16" configuration (BASELINE configs[4]); fp32 accumulate like f16
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum DType { DT_F32 = 0, DT_F16 = 1 };
-static inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : 4; }
+enum DType { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 template <typename T> struct TT;
 template <> struct TT<float> {
@@ -25,6 +29,10 @@ template <> struct TT<float> {
 template <> struct TT<f16> {
   static constexpr int SLOT = 8;
   typedef f16x8 vec;
+};
+template <> struct TT<bf16> {
+  static constexpr int SLOT = 8;
+  typedef bf16x8 vec;
 };
 
 constexpr int MAX_TAPS = 52;
@@ -105,9 +113,19 @@ struct WgradArgs {
 #if defined(__HIPCC__)
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: round to nearest even
+
+// one 32x32x16 matrix-core step on 16-bit fragments (8 k-values per lane), fp32 accumulate
+__device__ __forceinline__ f32x16 mma16(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Neighbouring tiles share data
 // (conv halos, the operand that several K groups / N tiles re-read), so give every XCD one CONTIGUOUS range of the logical

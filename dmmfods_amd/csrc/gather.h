@@ -306,6 +306,22 @@ __device__ __forceinline__ f16x8 bn_relu_slot(const f16x8& x, const SlotK<8>& k)
   }
   return __builtin_bit_cast(f16x8, o);
 }
+// bf16 has no mixed-precision fma: unpack by shift / mask (a bf16 is the upper half of an fp32), fma + max in fp32, one
+// v_cvt_pk_bf16_f32 per pair (7 instructions per 2 elements; 3 for f16)
+__device__ __forceinline__ bf16x8 bn_relu_slot(const bf16x8& x, const SlotK<8>& k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xi = __builtin_bit_cast(u32x4, x);
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float lo = __builtin_bit_cast(float, xi[p] << 16), hi = __builtin_bit_cast(float, xi[p] & 0xffff0000u);
+    bf16x2 pk;
+    pk[0] = (bf16)fmaxf(fmaf(lo, k.k0[2 * p], k.k1[2 * p]), 0.f);
+    pk[1] = (bf16)fmaxf(fmaf(hi, k.k0[2 * p + 1], k.k1[2 * p + 1]), 0.f);
+    o[p] = __builtin_bit_cast(unsigned, pk);
+  }
+  return __builtin_bit_cast(bf16x8, o);
+}
 __device__ __forceinline__ f32x4 bn_relu_slot(const f32x4& x, const SlotK<4>& k) {
   f32x4 o;
 #pragma unroll
@@ -333,6 +349,21 @@ __device__ __forceinline__ f16x8 eff_grad_slot(const f16x8& g, const f16x8& x, c
     o[p] = d;
   }
   return __builtin_bit_cast(f16x8, o);
+}
+__device__ __forceinline__ bf16x8 eff_grad_slot(const bf16x8& g, const bf16x8& x, const SlotK<8>& k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 gi = __builtin_bit_cast(u32x4, g), xi = __builtin_bit_cast(u32x4, x);
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float xl = __builtin_bit_cast(float, xi[p] << 16), xh = __builtin_bit_cast(float, xi[p] & 0xffff0000u);
+    const float gl = __builtin_bit_cast(float, gi[p] << 16), gh = __builtin_bit_cast(float, gi[p] & 0xffff0000u);
+    bf16x2 pk;
+    pk[0] = (bf16)(gl + fmaf(xl, k.k1[2 * p], k.k0[2 * p]));
+    pk[1] = (bf16)(gh + fmaf(xh, k.k1[2 * p + 1], k.k0[2 * p + 1]));
+    o[p] = __builtin_bit_cast(unsigned, pk);
+  }
+  return __builtin_bit_cast(bf16x8, o);
 }
 __device__ __forceinline__ f32x4 eff_grad_slot(const f32x4& g, const f32x4& x, const SlotK<4>& k) {
   f32x4 o;

@@ -460,6 +460,7 @@ hipError_t launch_halo_f32(const HaloArgs& h, int epi, hipStream_t st);  // halo
 // Returns hipErrorNotSupported when the layer is not eligible.
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   HaloArgs h;
+  if (dtype == DT_BF16) return hipErrorNotSupported;  // bf16 layers take the generic / thin kernels
   if (a.pool2 || !halo_plan(a, dtype, epi, h)) return hipErrorNotSupported;
   if (epi != EPI_BNBWD && a.seg[0].q != nullptr) return hipErrorNotSupported;
   if (epi == EPI_STORE && a.Npad > 64) return hipErrorNotSupported;

@@ -12,6 +12,7 @@
 // v_mfma_f32_32x32x16_f16 (or 32x32x2_f32) accumulators.  K advances in 64-byte chunks, register-staged
 // through a double-buffered LDS image with 80-byte rows (conflict-free ds_read_b128).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gather.h"
@@ -23,6 +24,9 @@ template <> struct Mma<f16> {
   static __device__ __forceinline__ void run(f32x16& acc, const f16x8& a, const f16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
   }
+};
+template <> struct Mma<bf16> {
+  static __device__ __forceinline__ void run(f32x16& acc, const bf16x8& a, const bf16x8& b) { acc = mma16(a, b, acc); }
 };
 template <> struct Mma<float> {
   // lane (r, h) holds k = 8s + 4h + i of row r: the i-th 32x32x2 MFMA pairs k(h=0,i) with k(h=1,i)
@@ -538,7 +542,11 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
   constexpr int P1 = EPI == EPI_BNBWD ? 2 : 1;  // the prologue this epilogue normally sees
   void (*kern)(const ConvArgs);
   int ai;
-  if (!mfma) { kern = igemm_kernel<T, BN, EPI, false, false, -1, KSV>; ai = 0; }
+  if (!mfma) {
+    // the scalar check kernels exist for fp32 / f16 (bring-up); bf16 arrived with the MFMA kernels already proven
+    if constexpr (std::is_same<T, bf16>::value) return hipErrorNotSupported;
+    else { kern = igemm_kernel<T, BN, EPI, false, false, -1, KSV>; ai = 0; }
+  }
   else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1, KSV> : igemm_kernel<T, BN, EPI, true, false, P1, KSV>; ai = lin ? 1 : 2; }
   else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0, KSV> : igemm_kernel<T, BN, EPI, true, false, 0, KSV>; ai = lin ? 3 : 4; }
   else { kern = igemm_kernel<T, BN, EPI, true, false, -1, KSV>; ai = 5; }
@@ -577,6 +585,28 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // halo.hip
 hipError_t launch_thin_logits(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // thin.hip
 
+// One translation unit per storage type (IGEMM_PART = 0 fp32, 1 f16, 2 bf16; see the Makefile): the ~50 kernel instantiations
+// of a type compile in parallel with the other types'.
+template <typename T>
+hipError_t launch_igemm_type(const ConvArgs& a, int epi, bool mfma, hipStream_t st) {
+  if (epi == EPI_STORE) return launch_epi<T, EPI_STORE>(a, mfma, st);
+  if (epi == EPI_BNBWD) return launch_epi<T, EPI_BNBWD>(a, mfma, st);
+  return launch_epi<T, EPI_LOGITS>(a, mfma, st);
+}
+#if !defined(IGEMM_PART) || IGEMM_PART == 0
+template hipError_t launch_igemm_type<float>(const ConvArgs&, int, bool, hipStream_t);
+#endif
+#if !defined(IGEMM_PART) || IGEMM_PART == 1
+template hipError_t launch_igemm_type<f16>(const ConvArgs&, int, bool, hipStream_t);
+#endif
+#if !defined(IGEMM_PART) || IGEMM_PART == 2
+template hipError_t launch_igemm_type<bf16>(const ConvArgs&, int, bool, hipStream_t);
+#endif
+
+#if !defined(IGEMM_PART) || IGEMM_PART == 1
+extern template hipError_t launch_igemm_type<float>(const ConvArgs&, int, bool, hipStream_t);
+extern template hipError_t launch_igemm_type<bf16>(const ConvArgs&, int, bool, hipStream_t);
+
 hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (mfma) {  // few output channels x many taps: gather once, reduce the taps in LDS
@@ -588,14 +618,10 @@ hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStr
     const hipError_t e = launch_halo(a, dtype, epi, st);
     if (e != hipErrorNotSupported) return e;
   }
-  if (dtype == DT_F16) {
-    if (epi == EPI_STORE) return launch_epi<f16, EPI_STORE>(a, mfma, st);
-    if (epi == EPI_BNBWD) return launch_epi<f16, EPI_BNBWD>(a, mfma, st);
-    return launch_epi<f16, EPI_LOGITS>(a, mfma, st);
-  }
-  if (epi == EPI_STORE) return launch_epi<float, EPI_STORE>(a, mfma, st);
-  if (epi == EPI_BNBWD) return launch_epi<float, EPI_BNBWD>(a, mfma, st);
-  return launch_epi<float, EPI_LOGITS>(a, mfma, st);
+  if (dtype == DT_F16) return launch_igemm_type<f16>(a, epi, mfma, st);
+  if (dtype == DT_BF16) return launch_igemm_type<bf16>(a, epi, mfma, st);
+  return launch_igemm_type<float>(a, epi, mfma, st);
 }
+#endif
 
 }  // namespace dmm

@@ -63,6 +63,7 @@ hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st)
   int grid = (int)((npix + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (dtype == DT_F16) hipLaunchKernelGGL(convert_input_kernel<f16>, dim3(grid), dim3(256), 0, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(convert_input_kernel<bf16>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(convert_input_kernel<float>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -217,13 +218,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
 }
 
 hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st) {
-  const int slot = dtype == DT_F16 ? 8 : 4;
+  const int slot = dtype == DT_F32 ? 4 : 8;
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.Hp * a.Wp;
   int grid = (npix + rpb - 1) / rpb;
   if (grid > 8192) grid = 8192;
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
   return hipGetLastError();
 }
@@ -303,13 +305,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
 }
 
 hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st) {
-  const int slot = dtype == DT_F16 ? 8 : 4;
+  const int slot = dtype == DT_F32 ? 4 : 8;
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.H0 * a.W0;
   int grid = (npix + rpb - 1) / rpb;
   if (grid > 8192) grid = 8192;
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), smem, st, a);
   return hipGetLastError();
 }
@@ -405,6 +408,7 @@ hipError_t launch_bce_metrics(const BceArgs& a, int dtype, hipStream_t st) {
   if (gx < 1) gx = 1;
   dim3 grid(gx, a.B);
   if (dtype == DT_F16) hipLaunchKernelGGL(bce_metrics_kernel<f16>, grid, dim3(256), 0, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(bce_metrics_kernel<bf16>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(bce_metrics_kernel<float>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -456,11 +460,12 @@ __global__ __launch_bounds__(256) void apply_corr_kernel(ApplyCorrArgs a) {
 }
 
 hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st) {
-  const size_t total = a.npix * (a.C / (dtype == DT_F16 ? 8 : 4));
+  const size_t total = a.npix * (a.C / (dtype == DT_F32 ? 4 : 8));
   int grid = (int)((total + 255) / 256);
   if (grid > 16384) grid = 16384;
   if (grid < 1) return hipSuccess;
   if (dtype == DT_F16) hipLaunchKernelGGL(apply_corr_kernel<f16>, dim3(grid), dim3(256), 0, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(apply_corr_kernel<bf16>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(apply_corr_kernel<float>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -557,6 +562,7 @@ hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int nde
   if (total_rows <= 0) return hipSuccess;
   dim3 grid((total_rows * 4 + 255) / 256), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(pack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
   else hipLaunchKernelGGL(pack_kernel<float>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
   return hipGetLastError();
 }
@@ -565,7 +571,7 @@ hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int n
                          hipStream_t st) {
   if (total_rows <= 0) return hipSuccess;
   dim3 grid((total_rows * 4 + 255) / 256), block(256);
-  if (dtype == DT_F16)
+  if (dtype != DT_F32)  // the packed gradient is fp32 for every storage type: only the chunk geometry (BK = 32) matters
     hipLaunchKernelGGL(unpack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows, grad_scale);
   else
     hipLaunchKernelGGL(unpack_kernel<float>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows, grad_scale);

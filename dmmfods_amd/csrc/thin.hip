@@ -27,11 +27,11 @@ constexpr int TH_RING = 6;        // output rows in flight: 2R+1 receive taps, o
 constexpr int TH_MAXTAPS = 32;
 
 struct ThinArgs {
-  const f16* src;
+  const void* src;   // T (f16 or bf16) NHWC
   int ld, B, H, W;
   const float* scale;
   const float* shift;
-  const f16* wpack;  // forward pack [chunk = tap*2 + c/32][Npad][32]
+  const void* wpack;  // T forward pack [chunk = tap*2 + c/32][Npad][32]
   int Npad, N, ntaps, R;
   float* logits;  // fp32 NCHW (B, N, H, W)
   int rows_per_wg, nys, nxs;
@@ -47,8 +47,11 @@ struct ThinSmem {
 
 // KR, KN: tap radius and class count at compile time (full row-major (2KR+1)^2 tap table), so that the reduction is
 // straight-line code with immediate LDS offsets.
-template <int KR, int KN>
+template <typename T, int KR, int KN>
 __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs a) {
+  typedef typename TT<T>::vec V8;
+  const T* const src = (const T*)a.src;
+  const T* const wpack = (const T*)a.wpack;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
   float* Ps = (float*)(smem + ThinSmem::A_BYTES);
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
 
   // ---- MFMA role: weight fragments of this lane's column, kept in registers for the whole strip ----
   const int r = lane & 31, h = lane >> 5;
-  f16x8 bfrag[2][2][3];
+  V8 bfrag[2][2][3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int col = 32 * t + r;
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bfrag[u][s][t][e] = (f16)0;
-        if (col < ncols) bfrag[u][s][t] = *(const f16x8*)(a.wpack + ((size_t)(tap * 2 + u) * a.Npad + cls) * 32 + (2 * s + h) * 8);
+        for (int e = 0; e < 8; ++e) bfrag[u][s][t][e] = (T)0;
+        if (col < ncols) bfrag[u][s][t] = *(const V8*)(wpack + ((size_t)(tap * 2 + u) * a.Npad + cls) * 32 + (2 * s + h) * 8);
       }
   }
 
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
   for (int i = tid; i < TH_RING * 4 * TH_PX; i += NTHREADS) Os[i] = 0.f;
 
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  f16x8 raw[4];
+  V8 raw[4];
   bool rawok[4];
   auto issue = [&](int iy) {
     const bool rowok = iy >= 0 && iy < a.H;
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
     for (int i = 0; i < 4; ++i) {
       rawok[i] = rowok && gxok[i];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) raw[i][e] = (f16)0;
-      if (rawok[i]) raw[i] = *(const f16x8*)(a.src + ((size_t)(b * a.H + iy) * a.W + gx[i]) * a.ld + 8 * j);
+      for (int e = 0; e < 8; ++e) raw[i][e] = (T)0;
+      if (rawok[i]) raw[i] = *(const V8*)(src + ((size_t)(b * a.H + iy) * a.W + gx[i]) * a.ld + 8 * j);
     }
   };
 
@@ -127,11 +130,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
     if (it < nsteps) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f16x8 v = bn_relu_slot(raw[i], kk);
-        f16x8 z;
+        const V8 v = bn_relu_slot(raw[i], kk);
+        V8 z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (f16)0;
-        *(f16x8*)(As + aoff + (pg + 32 * i) * ROWB) = rawok[i] ? v : z;  // zero padding applies AFTER BN+ReLU
+        for (int e = 0; e < 8; ++e) z[e] = (T)0;
+        *(V8*)(As + aoff + (pg + 32 * i) * ROWB) = rawok[i] ? v : z;  // zero padding applies AFTER BN+ReLU
       }
     }
     __syncthreads();  // A image complete; previous step's reduction has finished reading P
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void thin_logits_kernel(const ThinArgs
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const f16x8 av = *(const f16x8*)(As + (u * TH_PX + 32 * wave + r) * ROWB + (((2 * s + h) ^ ((r >> 2) & 3)) << 4));
+          const V8 av = *(const V8*)(As + (u * TH_PX + 32 * wave + r) * ROWB + (((2 * s + h) ^ ((r >> 2) & 3)) << 4));
 #pragma unroll
-          for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bfrag[u][s][t], acc[t], 0, 0, 0);
+          for (int t = 0; t < 3; ++t) acc[t] = mma16(av, bfrag[u][s][t], acc[t]);
         }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -202,7 +205,7 @@ void thin_set_enabled(bool on) { g_no_thin = !on; }
 
 // Returns hipErrorNotSupported when the layer is not eligible.
 hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t st) {
-  if (g_no_thin || dtype != DT_F16 || epi != EPI_LOGITS || c.nseg != 1) return hipErrorNotSupported;
+  if (g_no_thin || dtype == DT_F32 || epi != EPI_LOGITS || c.nseg != 1) return hipErrorNotSupported;
   const Seg& sg = c.seg[0];
   if (sg.mode != G_PLAIN || sg.istride != 1 || sg.Hs != c.Ho || sg.Ws != c.Wo || c.ostride != 1 || c.py != 0 || c.px != 0 ||
       c.Hout != c.Ho || c.Wout != c.Wo)
@@ -210,9 +213,9 @@ hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t
   if (sg.C != 64 || sg.Cpad != 64 || sg.scale == nullptr || sg.q != nullptr) return hipErrorNotSupported;
   if (c.N < 1 || c.N > 4 || sg.ntaps > TH_MAXTAPS || sg.ntaps * c.N > TH_COLS) return hipErrorNotSupported;
   ThinArgs a;
-  a.src = (const f16*)sg.src; a.ld = sg.ld; a.B = c.B; a.H = c.Ho; a.W = c.Wo;
+  a.src = sg.src; a.ld = sg.ld; a.B = c.B; a.H = c.Ho; a.W = c.Wo;
   a.scale = sg.scale; a.shift = sg.shift;
-  a.wpack = (const f16*)c.wpack; a.Npad = c.Npad; a.N = c.N; a.ntaps = sg.ntaps;
+  a.wpack = c.wpack; a.Npad = c.Npad; a.N = c.N; a.ntaps = sg.ntaps;
   a.logits = c.logits;
   // the kernel wants the full row-major (2R+1)^2 tap table
   int R = 0;
@@ -225,9 +228,10 @@ hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t
     a.dy[t] = (signed char)dy; a.dx[t] = (signed char)dx;
   }
   void (*kern)(const ThinArgs) = nullptr;
-  if (R == 2 && c.N == 3) kern = thin_logits_kernel<2, 3>;
-  else if (R == 2 && c.N == 1) kern = thin_logits_kernel<2, 1>;
-  else if (R == 2 && c.N == 2) kern = thin_logits_kernel<2, 2>;
+  const bool bf = dtype == DT_BF16;
+  if (R == 2 && c.N == 3) kern = bf ? thin_logits_kernel<bf16, 2, 3> : thin_logits_kernel<f16, 2, 3>;
+  else if (R == 2 && c.N == 1) kern = bf ? thin_logits_kernel<bf16, 2, 1> : thin_logits_kernel<f16, 2, 1>;
+  else if (R == 2 && c.N == 2) kern = bf ? thin_logits_kernel<bf16, 2, 2> : thin_logits_kernel<f16, 2, 2>;
   if (kern == nullptr) return hipErrorNotSupported;
   a.R = R;
   const int wout = TH_PX - 2 * R;

@@ -13,6 +13,7 @@
 // of rows; partial sums are added to dP with fp32 atomics (128-byte contiguous segments per wave instruction).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gather.h"
@@ -29,6 +30,7 @@ constexpr int KW = 128;  // k elements per workgroup
 
 template <typename T> struct WgCfg;
 template <> struct WgCfg<f16> { static constexpr int BMW = 64; };
+template <> struct WgCfg<bf16> { static constexpr int BMW = 64; };
 template <> struct WgCfg<float> { static constexpr int BMW = 32; };
 
 template <typename T, int WBN>
@@ -53,10 +55,18 @@ struct WgradSmem {
   static constexpr int bytes = 2 * BUF + TAB;
 };
 
-__device__ __forceinline__ f16x4 lds_tr16(const unsigned char* p) {
+// ds_read_b64_tr_b16 moves 16-bit elements whatever they encode: the result is handed back as two dwords
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
   typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
   h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(p));
-  return *(f16x4*)&r;
+  return __builtin_bit_cast(u32x2, r);
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec frag16(const u32x2& lo, const u32x2& hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(typename TT<T>::vec, v);
 }
 
 // PP / PQ = prologue kind of the pixel-aligned operand P and of the tapped operand Q (-1 run time, 0 none, 1 BN+ReLU,
@@ -265,20 +275,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
         for (int ms = 0; ms < BMW / 16; ++ms) {
           const int rowb = 16 * ms + 8 * (tg >> 1) + tq;
           const unsigned char* dp = Ds + rowb * SM::PD + dsw;
-          f16x4 lo = lds_tr16(dp), hi = lds_tr16(dp + 4 * SM::PD);
-          f16x8 af;
-          af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-          af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+          const V af = frag16<T>(lds_tr16(dp), lds_tr16(dp + 4 * SM::PD));
 #pragma unroll
           for (int t = 0; t < TPW; ++t) {
             const int kt = wk * TPW + t;
             const int acol = (32 * kt + 16 * (tg & 1) + 4 * tp) * 2;
             const unsigned char* ap = As + rowb * SM::PA + (SM::SWZ_A ? (acol ^ (tq << 6)) : acol);
-            f16x4 blo = lds_tr16(ap), bhi = lds_tr16(ap + 4 * SM::PA);
-            f16x8 bf;
-            bf[0] = blo[0]; bf[1] = blo[1]; bf[2] = blo[2]; bf[3] = blo[3];
-            bf[4] = bhi[0]; bf[5] = bhi[1]; bf[6] = bhi[2]; bf[7] = bhi[3];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+            const V bf = frag16<T>(lds_tr16(ap), lds_tr16(ap + 4 * SM::PA));
+            acc[t] = mma16(af, bf, acc[t]);
           }
         }
       } else {
@@ -378,7 +382,10 @@ static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
   const bool lin = a.nseg == 1 && seg_lin(a.seg[0], a) && seg_lin(a.dy, a);
   void (*kern)(const WgradArgs);
   int ai;
-  if (!mfma) { kern = wgrad_kernel<T, WBN, false, -1, -1, false, WDIST(WBN, -1, -1)>; ai = 0; }
+  if (!mfma) {
+    if constexpr (std::is_same<T, bf16>::value) return hipErrorNotSupported;  // no scalar check kernels for bf16 (see igemm.hip)
+    else { kern = wgrad_kernel<T, WBN, false, -1, -1, false, WDIST(WBN, -1, -1)>; ai = 0; }
+  }
   else if (lin && pp == 2 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 2, 1, true, WDIST(WBN, 2, 1)>; ai = 1; }
   else if (lin && pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, true, WDIST(WBN, 0, 1)>; ai = 7; }
   else if (pp == 0 && pq == 1) { kern = wgrad_kernel<T, WBN, true, 0, 1, false, WDIST(WBN, 0, 1)>; ai = 8; }
@@ -398,17 +405,32 @@ static hipError_t launch_w(const WgradArgs& a, bool mfma, hipStream_t st) {
 }
 
 template <typename T>
-static hipError_t launch_wt(const WgradArgs& a, bool mfma, hipStream_t st) {
+hipError_t launch_wt(const WgradArgs& a, bool mfma, hipStream_t st) {
   if (a.Npad % 128 == 0) return launch_w<T, 128>(a, mfma, st);
   if (a.Npad % 64 == 0) return launch_w<T, 64>(a, mfma, st);
   return launch_w<T, 32>(a, mfma, st);
 }
 
+// One translation unit per storage type (WGRAD_PART = 0 fp32, 1 f16, 2 bf16; see the Makefile).
+#if !defined(WGRAD_PART) || WGRAD_PART == 0
+template hipError_t launch_wt<float>(const WgradArgs&, bool, hipStream_t);
+#endif
+#if !defined(WGRAD_PART) || WGRAD_PART == 1
+template hipError_t launch_wt<f16>(const WgradArgs&, bool, hipStream_t);
+#endif
+#if !defined(WGRAD_PART) || WGRAD_PART == 2
+template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
+#endif
+
+#if !defined(WGRAD_PART) || WGRAD_PART == 1
+extern template hipError_t launch_wt<float>(const WgradArgs&, bool, hipStream_t);
+extern template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
+
 // Fills rows_per_split / kgroups (if zero) and launches.
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
-  const int BK = dtype == DT_F16 ? 32 : 16;
-  const int bmw = dtype == DT_F16 ? 64 : 32;
+  const int BK = dtype == DT_F32 ? 16 : 32;
+  const int bmw = dtype == DT_F32 ? 32 : 64;
   int total = 0;
   for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
   a.kgroups = (total * BK + KW - 1) / KW;
@@ -425,7 +447,10 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
     if (per < 4) per = 4;
     a.rows_per_split = per * bmw;
   }
-  return dtype == DT_F16 ? launch_wt<f16>(a, mfma, st) : launch_wt<float>(a, mfma, st);
+  if (dtype == DT_F16) return launch_wt<f16>(a, mfma, st);
+  if (dtype == DT_BF16) return launch_wt<bf16>(a, mfma, st);
+  return launch_wt<float>(a, mfma, st);
 }
+#endif
 
 }  // namespace dmm

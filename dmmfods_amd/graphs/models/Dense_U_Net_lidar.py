@@ -19,7 +19,8 @@ import torch.nn as nn
 from ... import _lib
 from ...utils.Dense_U_Net_lidar_helper import get_config
 
-_DTYPES = {"fp32": _lib.DMM_F32, "float32": _lib.DMM_F32, "fp16": _lib.DMM_F16, "float16": _lib.DMM_F16}
+_DTYPES = {"fp32": _lib.DMM_F32, "float32": _lib.DMM_F32, "fp16": _lib.DMM_F16, "float16": _lib.DMM_F16,
+           "bf16": _lib.DMM_BF16, "bfloat16": _lib.DMM_BF16}   # storage / MFMA operand type; accumulation is always fp32
 
 
 class _Node(nn.Module):

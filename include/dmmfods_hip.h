@@ -39,7 +39,7 @@ typedef enum {
   DMM_ERR_NO_DEVICE = -5
 } dmm_status;
 
-enum { DMM_F32 = 0, DMM_F16 = 1 };
+enum { DMM_F32 = 0, DMM_F16 = 1, DMM_BF16 = 2 };
 
 /* tensor kinds in the state_dict table */
 enum { DMM_T_CONV = 0, DMM_T_CONVT = 1, DMM_T_BN_WEIGHT = 2, DMM_T_BN_BIAS = 3, DMM_T_BN_MEAN = 4, DMM_T_BN_VAR = 5,
@@ -57,7 +57,7 @@ typedef struct {
   int32_t stream_1_in_channels;
   int32_t stream_2_in_channels;
   int32_t batch, height, width; /* per-GPU minibatch and input size (H, W multiples of 32) */
-  int32_t dtype;                /* DMM_F32 (parity) or DMM_F16 (storage/MFMA type; fp32 accumulate) */
+  int32_t dtype;                /* DMM_F32 (parity), DMM_F16 or DMM_BF16 (storage/MFMA type; fp32 accumulate) */
   float loss_scale;             /* multiplies d(loss)/d(logit); gradients are un-scaled before they are returned */
   float bn_momentum, bn_eps;    /* 0.1, 1e-5 */
   float iou_threshold;          /* config.agent.iou_threshold, 0.7, applied to raw logits (reference quirk) */

@@ -119,7 +119,8 @@ def test_full_size_c2_batch4_step_properties():
     pred, gt = logits >= 0.7, tgt >= 0.7
     inter, union = (pred & gt).sum(dim=(2, 3)).double(), (pred | gt).sum(dim=(2, 3)).double()
     assert torch.equal(met["intersection"].cpu(), inter.cpu()) and torch.equal(met["union"].cpu(), union.cpu())
-    eq = (pred == gt).sum(dim=(0, 2, 3)).double() / float(B * 1280 * 1920)
+    # per-sample counts first (the reduction torch also uses for the IoU counts above), then over the batch
+    eq = (pred == gt).sum(dim=(2, 3)).sum(dim=0).double() / float(B * 1280 * 1920)
     torch.testing.assert_close(met["acc_per_class"].double().cpu(), eq.cpu(), rtol=1e-6, atol=1e-7)
     ga = model.grad_arena
     assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
@@ -169,6 +170,40 @@ def test_fp16_training_trajectory_tracks_fp32_oracle():
     print("fp16 trajectory: per-step max rel loss deviation", ["%.2e" % d for d in devs], "step-0 grad rel L2 vs fp16 emulation %.3e" % g_err)
     assert max(devs) < 1e-2, devs          # measured 1e-4 .. 2e-3
     assert g_err < 0.08, g_err             # measured ~3e-2
+
+
+def test_bf16_storage_d201_mid3_against_oracle_emulation():
+    """BASELINE configs[4] arithmetic ("mixed bf16": bf16 storage and MFMA operands, fp32 accumulation) on its architecture
+    (DenseNet-201, fusion before block 3) at a small size: logits, loss sums and the global gradient error against the oracle's
+    bf16-storage emulation (fp64 arithmetic, rounding where the HIP path stores bf16), with the emulation's own distance from
+    the unrounded fp64 run as the yardstick."""
+    from oracle import restatement as R
+    arch = _arch(R, R.DENSENETS[201], "mid3")
+    B, H, W = 2, 64, 96
+    ob, gb = _oracle_grads(R, arch, torch.float64, B, H, W, seed=13, wseed=77, storage=torch.bfloat16)
+    o64, g64 = _oracle_grads(R, arch, torch.float64, B, H, W, seed=13, wseed=77)
+    model = _model(arch, "bf16", factory="densenet201_u_lidar")
+    model.load_state_dict(R.make_state(arch, seed=77))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, B, H, W, seed=13)
+    logits = model(rgb.to(DEV), lidar.to(DEV))
+    met = model.loss_backward(tgt.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(model.grad_arena).all()
+    e_log, y_log = _rel(logits.detach(), ob["logits"]), _rel(ob["logits"], o64["logits"])
+    e_loss = _rel(met["loss_per_class"], ob["loss_per_class"])
+    num = den = ynum = 0.0
+    for k, p in model.named_parameters():
+        num += float((p.grad.detach().cpu().double() - gb[k]).pow(2).sum())
+        ynum += float((gb[k] - g64[k]).pow(2).sum())
+        den += float(gb[k].pow(2).sum())
+    e_g, y_g = (num / den) ** 0.5, (ynum / den) ** 0.5
+    print(f"bf16 d201 mid3: logits {e_log:.3e} (emulation vs fp64 {y_log:.3e}), loss {e_loss:.3e}, grads rel L2 {e_g:.3e} (emulation vs fp64 {y_g:.3e})")
+    # bf16 keeps 8 significant bits: the storage rounding itself moves the logits by y_log; the HIP path may differ from the
+    # emulation by as much again (different summation order meeting the same rounding points)
+    assert e_log < max(5e-2, 2 * y_log), (e_log, y_log)
+    assert e_loss < 2e-2, e_loss
+    assert e_g < max(0.15, 2 * y_g), (e_g, y_g)
 
 
 @pytest.mark.parametrize("variant,H,W", [("early", 32, 32), ("mid3", 32, 96), ("no", 96, 32), ("mid2", 160, 64), ("mid4", 224, 96),

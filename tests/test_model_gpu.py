@@ -193,14 +193,14 @@ def test_tiny_training_step_fp16(variant):
     logits = model(rgb.to(DEV), lidar.to(DEV))
     met = model.loss_backward(tgt.to(DEV))
     torch.cuda.synchronize()
-    assert _rel(logits.detach(), oh["logits"]) < 3e-2
+    assert _rel(logits.detach(), oh["logits"]) < 2e-2        # measured 0.6e-2 / 1.1e-2
     assert _rel(met["loss_per_class"], oh["loss_per_class"]) < 2e-3
     num = den = 0.0
     for k, p in model.named_parameters():
         num += (p.grad.detach().cpu().double() - gh[k]).pow(2).sum().item()
         den += gh[k].pow(2).sum().item()
     print(f"tiny fp16 {variant}: grad rel L2 vs the fp16-storage emulation {(num / den) ** 0.5:.3e}, logits {_rel(logits.detach(), oh['logits']):.3e}")
-    assert (num / den) ** 0.5 < 0.15
+    assert (num / den) ** 0.5 < 0.09        # measured 6.2e-2 (early) / 2.9e-2 (mid3): fp16 storage rounding of cancelling BatchNorm sums
 
 
 def test_c1_densenet121_golden_and_directional_derivative(golden_dir):
