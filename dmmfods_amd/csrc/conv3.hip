@@ -1,0 +1,483 @@
+// Multi-tap convolutions on an LDS halo tile, gfx950, 16-bit storage types:
+//   * the dense layers' 3x3 growth convolution, forward and data gradient (torchvision _DenseLayer.conv2, 128 -> 32 channels;
+//     reference call sites M:85-92, M:169-176);
+//   * the heat-map head's first convolution `refine0` (reference M:126-127): forward, in the per-output-parity form of plan.cpp
+//     (2x2 merged taps over the half-resolution decoder output, 128 channels, plus 3x3 stride-2 taps over the raw input,
+//     8 channels; 64 output channels), and its data gradient towards the raw input.
+//
+// The generic implicit-GEMM kernel (igemm.hip) gathers, bounds-tests and normalises the input once per TAP: 9x (4x) the
+// BatchNorm+ReLU arithmetic and address work for 8 MFMAs per tap - 58 vector instructions per MFMA on the growth convolution.
+// Here a workgroup owns an 8 x 16 pixel tile of the row grid:
+//   1. the input halo (tile + tap extent) of every segment is loaded ONCE (16-byte slots, all loads in flight together,
+//      branch-free), the prologue (BN+ReLU, or the deferred BatchNorm-backward correction g + q + r*x for data gradients) is
+//      applied ONCE per element and the result is written to an LDS image [halo row][halo pixel][channel]; pixels outside the
+//      picture are zero AFTER the prologue, as in conv(relu(bn(x)));
+//   2. the K loop walks the packed-weight chunks in groups: a tap only shifts the LDS address of the A fragment, the weights
+//      stream through a 3-deep ring filled by LDS-DMA two groups ahead (global_load_lds_dwordx4 from inline asm, swizzle on the
+//      source address; counted vmcnt + raw s_barrier, so the DMA stays in flight across the barrier);
+//   3. epilogues as in igemm.hip: store + BatchNorm statistics (forward; the statistics are reduced straight from the
+//      accumulator layout), or fused BN/ReLU backward (data gradient).
+// LDS image of the wide segment: pixel pitch = C*2 + 16 bytes (an odd number of 16-byte slots), row pitch a multiple of 256
+// bytes: the 16 lanes of a ds_read_b128 group (pixels x = 0-3, 12-15 of one tile row and 4-11 of the next) hit 16 different slots.
+// Two workgroups share a CU (<= 80 KB of LDS each): one fills its halo while the other runs its MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "gather.h"
+
+namespace dmm {
+
+constexpr int C3_TH = 8, C3_TW = 16;
+constexpr int C3_WRING = 3;  // weight ring slots
+
+struct Conv3Args {
+  ConvArgs c;
+  int tiles_y, tiles_x;
+  int dymin0, dxmin0;  // smallest tap offsets of segment 0 (its halo starts there)
+  int dymin1, dxmin1;  // ... of the raw-input segment (stride-2 source)
+  int dbg;             // timing experiments (DMM_C3_DBG): 1 halo loads hit one line, 2 no MFMA, 4 no weight DMA, 8 no epilogue,
+                       // 16 no global statistics atomics, 32 no statistics at all
+};
+
+// CS = 16-byte channel slots per pixel of segment 0 (C = 8 CS, a multiple of 32); SPAN = tap extent - 1 (2: 3x3, 1: 2x2);
+// SEG1: a second segment of 8 channels, nine stride-2 taps (three K chunks); NT = 32-column output tiles; GC = chunks per ring slot.
+template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC>
+struct Conv3Cfg {
+  static constexpr int BN = 32 * NT;
+  static constexpr int NTAPS0 = (SPAN + 1) * (SPAN + 1), CG = CS / 4;
+  static constexpr int NCH0 = NTAPS0 * CG, NCH = NCH0 + (SEG1 ? 3 : 0);
+  static constexpr int NGRP = (NCH + GC - 1) / GC;
+  static constexpr int HH = C3_TH + SPAN, HW = C3_TW + SPAN;
+  static constexpr int PP = CS * 16 + 16;
+  static constexpr int RP = (HW * PP + 255) / 256 * 256;
+  static constexpr int HALO0 = HH * RP;
+  static constexpr int HH1 = 2 * (C3_TH - 1) + 3, HW1 = 2 * (C3_TW - 1) + 3;  // 3x3 stride-2 taps: 17 x 33 source pixels
+  static constexpr int RP1 = HW1 * 16;
+  static constexpr int HALO1 = SEG1 ? HH1 * RP1 : 0;
+  static constexpr int WSLOT = GC * BN * 64;
+  static constexpr int MAIN0 = HALO0 + HALO1 + C3_WRING * WSLOT;
+  static constexpr int STAGE = BM * (BN + 8) * 2;  // accumulators staged as T (16-bit) for both epilogues
+  static constexpr int MAIN = MAIN0 > STAGE ? MAIN0 : STAGE;
+  static constexpr int EXTRA = BM * 4 + 2 * BN * 8 + 4 * 2 * BN * 4;  // rowpix + fp64 reduction scratch + per-wave partials
+  static constexpr int bytes = MAIN + EXTRA;
+};
+
+// PRO = 0 none, 1 BN+ReLU, 2 effective gradient (16-bit form: q, r only).
+template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC, int EPI, int PRO>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
+  static_assert(sizeof(T) == 2 && CS % 4 == 0, "16-bit storage, whole 64-byte chunks");
+  typedef typename TT<T>::vec V;
+  typedef Conv3Cfg<T, CS, SPAN, SEG1, NT, GC> SM;
+  constexpr int SLOT = 8, BN = SM::BN, CG = SM::CG, NCH0 = SM::NCH0, NCH = SM::NCH, NGRP = SM::NGRP;
+  constexpr int PP = SM::PP, RP = SM::RP, RP1 = SM::RP1, HH = SM::HH, HW = SM::HW;
+  constexpr int NSL = HH * HW * CS;                    // halo slots of segment 0 per tile
+  constexpr int NI = (NSL + NTHREADS - 1) / NTHREADS;  // per thread
+  constexpr int PSTEP = NTHREADS / CS;                 // halo pixels between a thread's consecutive slots
+  constexpr int NSL1 = SM::HH1 * SM::HW1;
+  constexpr int NI1 = SEG1 ? (NSL1 + NTHREADS - 1) / NTHREADS : 0;
+  constexpr int PPC = BN / 16;                         // 1-KiB weight pieces per chunk
+  constexpr int NPW = (GC * PPC) / 4;                  // ... per wave and ring slot
+  static_assert((GC * BN) % 64 == 0 && NTHREADS % CS == 0, "weight pieces must split evenly over the waves");
+  const ConvArgs& a = g.c;
+  const Seg& sg = a.seg[0];
+  const Seg& sg1 = a.seg[SEG1 ? 1 : 0];
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo = smem;
+  unsigned char* halo1 = smem + SM::HALO0;
+  unsigned char* wring = smem + SM::HALO0 + SM::HALO1;
+  int* rowpix = (int*)(smem + SM::MAIN);
+  double* red = (double*)(smem + SM::MAIN + BM * 4);
+  float* wpart = (float*)(smem + SM::MAIN + BM * 4 + 2 * BN * 8);  // [wave][2][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
+  const int ty_i = tile % g.tiles_y;
+  const int b = tile / g.tiles_y;
+  const int y0 = ty_i * C3_TH, x0 = tx_i * C3_TW;
+
+  // ---- the first two weight groups start streaming now ----
+  // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain it (vmcnt(0)) in front of the next ds_read
+  // as it does for the builtin (it cannot prove that the LDS ranges differ); the waits are the counted ones in the K loop.
+  const T* wp = (const T*)a.wpack;
+  int woff[NPW];   // per-lane source offset (elements) inside a group's block (the group's chunks are contiguous: Npad == BN)
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int row = 16 * (wave * NPW + q) + (lane >> 2);
+    woff[q] = row * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);   // swizzle on the source side
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wdst0 = __builtin_amdgcn_readfirstlane(lds0 + SM::HALO0 + SM::HALO1 + wave * NPW * 1024);
+  auto issue_w = [&](int grp) {
+    if (g.dbg & 4) return;
+    const unsigned dst = wdst0 + (grp % C3_WRING) * SM::WSLOT;
+    const T* src = wp + (size_t)grp * (GC * BN * 32);
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+      // a piece of a chunk past the end of the pack (last, partial group) re-reads the chunk before it: never used
+      const int gc = (wave * NPW + q) / PPC;
+      const T* s = (grp * GC + gc < NCH) ? src : src - (size_t)(grp * GC + gc - (NCH - 1)) * (BN * 32);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(s + woff[q]), "s"(dst + q * 1024) : "memory");
+    }
+  };
+  issue_w(0);
+  if (NGRP > 1) issue_w(1);
+
+  // ---- halo: every slot loaded once, all loads in flight together ----
+  const int cs = tid % CS, hp0 = tid / CS;
+  SlotK<SLOT> kk, kk1;
+  kk.k0 = 0.f; kk.k1 = 0.f; kk.k2 = 0.f; kk.k3 = 0.f;
+  kk1 = kk;
+  if (PRO == 1) { kk.k0 = load_fv<SLOT>(sg.scale + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.shift + cs * SLOT); }
+  if (PRO == 2) { kk.k0 = load_fv<SLOT>(sg.q + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.r + cs * SLOT); }
+  if (SEG1 && PRO == 1) { kk1.k0 = load_fv<SLOT>(sg1.scale); kk1.k1 = load_fv<SLOT>(sg1.shift); }
+  V raw[NI], raw2[PRO == 2 ? NI : 1], rawb[SEG1 ? NI1 : 1];
+  bool ok[NI], okb[SEG1 ? NI1 : 1];
+  const T* src = (const T*)sg.src + cs * SLOT;
+  const T* src2 = (const T*)sg.src2 + cs * SLOT;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int hp = hp0 + PSTEP * i;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int sy = y0 + g.dymin0 + hy, sx = x0 + g.dxmin0 + hx;
+    ok[i] = hp < HH * HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws;
+    // branch-free: a slot outside the picture loads a clamped (valid) address and is zeroed when the image is written; a
+    // conditional load would make the compiler wait for each load before the next branch
+    const int cy = min(max(sy, 0), sg.Hs - 1), cx = min(max(sx, 0), sg.Ws - 1);
+    const size_t pix = (g.dbg & 1) ? 0 : (size_t)(b * sg.Hs + cy) * sg.Ws + cx;
+    raw[i] = *(const V*)(src + pix * sg.ld);
+    if constexpr (PRO == 2) raw2[i] = *(const V*)(src2 + pix * sg.ld2);
+  }
+  if constexpr (SEG1) {
+#pragma unroll
+    for (int i = 0; i < NI1; ++i) {
+      const int hp = tid + NTHREADS * i;
+      const int hy = hp / SM::HW1, hx = hp - hy * SM::HW1;
+      const int sy = 2 * y0 + g.dymin1 + hy, sx = 2 * x0 + g.dxmin1 + hx;
+      okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
+      const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
+      const size_t pix = (g.dbg & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
+      rawb[i] = *(const V*)((const T*)sg1.src + pix * sg1.ld);
+    }
+  }
+  if (tid < BM) {
+    const int y = y0 + tid / C3_TW, x = x0 + tid % C3_TW;
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
+  }
+  if (tid < 2 * BN) red[tid] = 0.0;
+
+  // ---- epilogue operands of the fused BN/ReLU backward: x at every output position, issued now, used after the K loop ----
+  constexpr int NCV = BN / SLOT;       // slot columns of the output tile
+  constexpr int RPP = NTHREADS / NCV;  // rows per pass
+  constexpr int NIT = BM / RPP;        // rows per thread
+  const int cv = tid % NCV, rr = tid / NCV;
+  const int n = cv * SLOT;
+  const bool colvalid = n < a.N;
+  int ppre[EPI == EPI_BNBWD ? NIT : 1];
+  V xpre[EPI == EPI_BNBWD ? NIT : 1];
+  if constexpr (EPI == EPI_BNBWD) {
+    const T* bx = (const T*)a.bx;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {  // (rowpix is not visible yet: recompute this thread's rows)
+      const int row = rr + RPP * i;
+      const int y = y0 + row / C3_TW, x = x0 + row % C3_TW;
+      ppre[i] = (colvalid && y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) xpre[i][e] = (T)0;
+      if (ppre[i] >= 0) xpre[i] = *(const V*)(bx + (size_t)ppre[i] * a.ldbx + n);
+    }
+  }
+
+  // ---- prologue once per element, then the LDS images ----
+  V z;
+#pragma unroll
+  for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int hp = hp0 + PSTEP * i;
+    if (hp < HH * HW) {
+      const int hy = hp / HW, hx = hp - hy * HW;
+      V v = raw[i];
+      if constexpr (PRO == 1) v = bn_relu_slot(raw[i], kk);
+      if constexpr (PRO == 2) v = eff_grad_slot(raw[i], raw2[i], kk);
+      *(V*)(halo + hy * RP + hx * PP + cs * 16) = ok[i] ? v : z;  // zero padding applies AFTER the prologue
+    }
+  }
+  if constexpr (SEG1) {
+#pragma unroll
+    for (int i = 0; i < NI1; ++i) {
+      const int hp = tid + NTHREADS * i;
+      if (hp < NSL1) {
+        V v = rawb[i];
+        if constexpr (PRO == 1) v = bn_relu_slot(rawb[i], kk1);
+        *(V*)(halo1 + hp * 16) = okb[i] ? v : z;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first two weight groups (issued first) and every load after them
+  __syncthreads();                                   // images + first two ring slots complete
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // this lane's pixel: tile row 2*wave + (r >> 4), column r & 15
+  const int ty = 2 * wave + (r >> 4), tx = r & 15;
+  const int abase = (ty - g.dymin0) * RP + (tx - g.dxmin0) * PP + h * 16;
+  const int bsw = (r >> 2) & 3;
+  // tap offsets: scalar loads from the kernel arguments, all before the loop - no compiler-counted memory operation may sit
+  // between the DMA issue and the counted wait, or hipcc's wait for it drains the DMA as well
+  int toffs[SM::NTAPS0];
+#pragma unroll
+  for (int tap = 0; tap < SM::NTAPS0; ++tap) {
+    const int tw = sg.taps[tap];
+    toffs[tap] = (int)(signed char)(tw & 0xff) * RP + (int)(signed char)((tw >> 8) & 0xff) * PP;
+  }
+  // segment 1: one 16-byte slot per tap; k-step (chunk c, half s) of lane half h reads tap j = 4c + 2s + h (j >= 9: zeros)
+  int off1[SEG1 ? 6 : 1];
+  if constexpr (SEG1) {
+    const int abase1 = (2 * ty - g.dymin1) * RP1 + (2 * tx - g.dxmin1) * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j0 = 4 * c + 2 * s;  // tap of lane half 0; half 1 reads j0 + 1
+        const int t0 = sg1.taps[j0 < 9 ? j0 : 0], t1 = sg1.taps[j0 + 1 < 9 ? j0 + 1 : 0];
+        const int o0 = (int)(signed char)(t0 & 0xff) * RP1 + (int)(signed char)((t0 >> 8) & 0xff) * 16;
+        const int o1 = (int)(signed char)(t1 & 0xff) * RP1 + (int)(signed char)((t1 >> 8) & 0xff) * 16;
+        off1[2 * c + s] = (j0 + h < 9) ? abase1 + (h ? o1 : o0) : -1;
+      }
+  }
+
+#pragma unroll
+  for (int grp = 0; grp < NGRP; ++grp) {
+    if (grp + 2 < NGRP) issue_w(grp + 2);  // ring slot (grp + 2) % 3 was last read during grp - 1: all waves are past its barrier
+    const unsigned char* Bp = wring + (grp % C3_WRING) * SM::WSLOT;
+    if (!(g.dbg & 2)) {
+#pragma unroll
+      for (int gc = 0; gc < GC; ++gc) {
+        const int ck = grp * GC + gc;
+        if (ck < NCH) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            V av = z;
+            if (ck < NCH0) {
+              av = *(const V*)(halo + abase + toffs[ck / CG] + (ck % CG) * 64 + s * 32);
+            } else if constexpr (SEG1) {
+              const int o = off1[2 * (ck - NCH0) + s];
+              const V ld = *(const V*)(halo1 + (o >= 0 ? o : 0));
+              av = o >= 0 ? ld : z;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const V bv = *(const V*)(Bp + (gc * BN + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
+              acc[t] = mma16(av, bv, acc[t]);
+            }
+          }
+        }
+      }
+    }
+    // the next group's weights (issued one iteration ago) must have landed; this iteration's DMA stays in flight
+    if (grp + 2 < NGRP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if ((g.dbg & 8) && acc[0][0] != 123.f) return;
+  // all waves are past the last barrier: the images and the ring are dead, reuse them for staging
+  T* Cs = (T*)smem;
+  constexpr int CPITCH = BN + 8;
+  float ps1[NT], ps2[NT];  // forward: this lane's column sums over its 16 rows, of the values as stored (rounded to T)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ps1[t] = 0.f; ps2[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const T v = from_f32<T>(acc[t][i]);
+      Cs[row * CPITCH + 32 * t + r] = v;
+      if (EPI == EPI_STORE && rowpix[row] >= 0) { const float f = to_f32(v); ps1[t] += f; ps2[t] = fmaf(f, f, ps2[t]); }
+    }
+  }
+  if constexpr (EPI == EPI_STORE) {
+    // BatchNorm statistics straight from the accumulator layout: lane (r, h) holds column 32 t + r; fold the two lane halves,
+    // one LDS word per column and wave, fp64 from there on (per-lane partials cover 16 rows: fp32 is exact enough, see igemm.hip)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      ps1[t] += __shfl_xor(ps1[t], 32, 64);
+      ps2[t] += __shfl_xor(ps2[t], 32, 64);
+      if (h == 0) { wpart[(wave * 2 + 0) * BN + 32 * t + r] = ps1[t]; wpart[(wave * 2 + 1) * BN + 32 * t + r] = ps2[t]; }
+    }
+  }
+  __syncthreads();
+
+  if constexpr (EPI == EPI_STORE) {
+    T* out = (T*)a.out;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int row = rr + RPP * i;
+      const int pix = rowpix[row];
+      if (pix < 0 || !colvalid) continue;
+      *(V*)(out + (size_t)pix * a.ldo + n) = *(const V*)(Cs + row * CPITCH + cv * SLOT);
+    }
+    if (a.stat_sum == nullptr || (g.dbg & 32)) return;
+    if (!(g.dbg & 16) && tid < 2 * BN) {
+      const int col = tid % BN, which = tid / BN;
+      if (col < a.N) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += (double)wpart[(w * 2 + which) * BN + col];
+        const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+        atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + col, s);
+      }
+    }
+    return;
+  } else {  // EPI_BNBWD: acc = d(relu(bn(x))); mask, reduce, scatter s*dz (see igemm.hip)
+    float s1[SLOT], s2[SLOT];
+#pragma unroll
+    for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    T* gout = (T*)a.out;
+    float sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+    if (colvalid) {
+      load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
+      load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      if (ppre[i] < 0) continue;
+      const int row = rr + RPP * i;
+      float av[SLOT], xf[SLOT], gf[SLOT];
+      vec_to_f32<T>(*(const V*)(Cs + row * CPITCH + cv * SLOT), av);
+      vec_to_f32<T>(xpre[i], xf);
+      if (a.accumulate && gout != nullptr) vec_to_f32<T>(*(const V*)(gout + (size_t)ppre[i] * a.ldo + n), gf);
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) {
+        const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+        s1[e] += dz;
+        s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+        gf[e] = ((a.accumulate && gout != nullptr) ? gf[e] : 0.f) + sc[e] * dz;
+      }
+      if (gout != nullptr) *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
+    }
+    if (g.dbg & 32) return;
+    // per-channel reductions: lanes -> LDS (fp64) -> one fp64 atomic per channel and workgroup (see igemm.hip)
+#pragma unroll
+    for (int i = 0; i < SLOT; ++i) {
+#pragma unroll
+      for (int d = NCV; d < 64; d <<= 1) {
+        s1[i] += __shfl_xor(s1[i], d, 64);
+        s2[i] += __shfl_xor(s2[i], d, 64);
+      }
+    }
+    if (colvalid && lane < NCV) {
+#pragma unroll
+      for (int i = 0; i < SLOT; ++i) {
+        atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
+        atomicAdd(&red[BN + cv * SLOT + i], (double)s2[i]);
+      }
+    }
+    __syncthreads();
+    if (!(g.dbg & 16) && tid < BN && tid < a.N) {
+      const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+      atomic_add_f64(a.red1 + rep + tid, red[tid]);
+      atomic_add_f64(a.red2 + rep + tid, red[BN + tid]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static bool g_conv3 = getenv("DMM_NO_CONV3") == nullptr;
+void conv3_set_enabled(bool on) { g_conv3 = on; }
+
+template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC, int EPI, int PRO>
+static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
+  typedef Conv3Cfg<T, CS, SPAN, SEG1, NT, GC> SM;
+  static_assert(SM::bytes <= 80 * 1024, "two workgroups per CU");
+  auto kern = conv3_kernel<T, CS, SPAN, SEG1, NT, GC, EPI, PRO>;
+  static bool attr_done = false;
+  if (SM::bytes > 48 * 1024 && !attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.c.B * g.tiles_y * g.tiles_x), dim3(NTHREADS), SM::bytes, st, g);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_c3_type(const Conv3Args& g, int epi, int pro, int cs, int span, bool seg1, int nt, hipStream_t st) {
+  if (epi == EPI_STORE && pro == 1) {
+    if (!seg1 && span == 2 && nt == 1 && cs == 16) return launch_c3<T, 16, 2, false, 1, 4, EPI_STORE, 1>(g, st);  // dense conv2
+    if (!seg1 && span == 2 && nt == 1 && cs == 8) return launch_c3<T, 8, 2, false, 1, 2, EPI_STORE, 1>(g, st);
+    if (seg1 && span == 1 && nt == 2 && cs == 16) return launch_c3<T, 16, 1, true, 2, 2, EPI_STORE, 1>(g, st);    // refine0 phase
+  }
+  if (epi == EPI_BNBWD && !seg1 && span == 2) {
+    if (cs == 4 && nt == 4 && pro == 2) return launch_c3<T, 4, 2, false, 4, 1, EPI_BNBWD, 2>(g, st);              // dense conv2 dgrad
+    if (cs == 4 && nt == 4 && pro == 0) return launch_c3<T, 4, 2, false, 4, 1, EPI_BNBWD, 0>(g, st);
+    if (cs == 4 && nt == 2 && pro == 2) return launch_c3<T, 4, 2, false, 2, 1, EPI_BNBWD, 2>(g, st);
+    if (cs == 4 && nt == 2 && pro == 0) return launch_c3<T, 4, 2, false, 2, 1, EPI_BNBWD, 0>(g, st);
+    if (cs == 8 && nt == 1 && pro == 0) return launch_c3<T, 8, 2, false, 1, 2, EPI_BNBWD, 0>(g, st);              // refine0 -> raw input
+    if (cs == 8 && nt == 1 && pro == 2) return launch_c3<T, 8, 2, false, 1, 2, EPI_BNBWD, 2>(g, st);
+  }
+  return hipErrorNotSupported;
+}
+
+static bool tap_box(const Seg& sg, int& dymin, int& dxmin, int& span) {
+  int dymax = -128, dxmax = -128;
+  dymin = 127; dxmin = 127;
+  for (int t = 0; t < sg.ntaps; ++t) {
+    const int dy = (int)(signed char)(sg.taps[t] & 0xff), dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff);
+    dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax;
+    dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+  }
+  span = dymax - dymin;
+  if (span < 0 || span > 3 || dxmax - dxmin != span || sg.ntaps != (span + 1) * (span + 1)) return false;
+  bool seen[16] = {false};
+  for (int t = 0; t < sg.ntaps; ++t) {  // every offset of the box exactly once, in any order
+    const int dy = (int)(signed char)(sg.taps[t] & 0xff) - dymin, dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff) - dxmin;
+    if (seen[dy * (span + 1) + dx]) return false;
+    seen[dy * (span + 1) + dx] = true;
+  }
+  return true;
+}
+
+// Returns hipErrorNotSupported when the layer is not one of the shapes built (16-bit storage, unit-stride multi-tap segment of
+// C % 32 == 0 channels on the row grid, optionally the 8-channel stride-2 raw-input segment of the head).
+hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
+  if (!g_conv3 || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2 || a.pool2 || (epi != EPI_STORE && epi != EPI_BNBWD)) return hipErrorNotSupported;
+  const Seg& sg = a.seg[0];
+  if (sg.mode != G_PLAIN || sg.istride != 1 || sg.C % 32 || sg.Cpad != sg.C || sg.Hs != a.Ho || sg.Ws != a.Wo) return hipErrorNotSupported;
+  if (a.Npad % 32 || a.Npad > 128) return hipErrorNotSupported;
+  Conv3Args g;
+  g.c = a;
+  int span = 0, span1 = 0;
+  g.dymin1 = g.dxmin1 = 0;
+  if (!tap_box(sg, g.dymin0, g.dxmin0, span) || span < 1 || span > 2) return hipErrorNotSupported;
+  const bool seg1 = a.nseg == 2;
+  if (seg1) {
+    const Seg& s1 = a.seg[1];
+    if (s1.mode != G_PLAIN || s1.istride != 2 || s1.C != 8 || s1.Cpad != 8 || s1.ntaps != 9 || s1.Hs != 2 * a.Ho || s1.Ws != 2 * a.Wo ||
+        (s1.scale != nullptr) != (sg.scale != nullptr) || s1.q != nullptr)
+      return hipErrorNotSupported;
+    if (!tap_box(s1, g.dymin1, g.dxmin1, span1) || span1 != 2) return hipErrorNotSupported;
+  } else if (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo) {
+    return hipErrorNotSupported;
+  }
+  const int pro = sg.scale ? 1 : (sg.q ? 2 : 0);
+  if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
+  g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
+  g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
+  static const int dbg = getenv("DMM_C3_DBG") ? atoi(getenv("DMM_C3_DBG")) : 0;
+  g.dbg = dbg;
+  const int cs = sg.C / 8, nt = a.Npad / 32;
+  return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, seg1, nt, st)
+                         : launch_c3_type<bf16>(g, epi, pro, cs, span, seg1, nt, st);
+}
+
+}  // namespace dmm
