@@ -20,6 +20,7 @@
 // LDS image of the wide segment: pixel pitch = C*2 + 16 bytes (an odd number of 16-byte slots), row pitch a multiple of 256
 // bytes: the 16 lanes of a ds_read_b128 group (pixels x = 0-3, 12-15 of one tile row and 4-11 of the next) hit 16 different slots.
 // Two workgroups share a CU (<= 80 KB of LDS each): one fills its halo while the other runs its MFMAs.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -40,19 +41,23 @@ struct Conv3Args {
                        // 16 no global statistics atomics, 32 no statistics at all
 };
 
-// CS = 16-byte channel slots per pixel of segment 0 (C = 8 CS, a multiple of 32); SPAN = tap extent - 1 (2: 3x3, 1: 2x2);
-// SEG1: a second segment of 8 channels, nine stride-2 taps (three K chunks); NT = 32-column output tiles; GC = chunks per ring slot.
-template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC>
+// CS = 16-byte channel slots per pixel of the wide segment (C = 8 CS, a multiple of 32; 0: no wide segment); SPAN = its tap
+// extent - 1 (2: 3x3, 1: 2x2).  TSPAN / TSTR: a thin segment of 8 channels (ONE slot per pixel) with (TSPAN+1)^2 taps at source
+// stride TSTR (TSPAN = -1: none): the head's raw-input taps (3x3, stride 2) or the logits gradient under the 5x5 conv (stride 1).
+// NT = 32-column output tiles; GC = chunks per ring slot.
+template <typename T, int CS, int SPAN, int TSPAN, int TSTR, int NT, int GC>
 struct Conv3Cfg {
+  static constexpr bool SEG0 = CS > 0, SEG1 = TSPAN >= 0;
   static constexpr int BN = 32 * NT;
-  static constexpr int NTAPS0 = (SPAN + 1) * (SPAN + 1), CG = CS / 4;
-  static constexpr int NCH0 = NTAPS0 * CG, NCH = NCH0 + (SEG1 ? 3 : 0);
+  static constexpr int NTAPS0 = SEG0 ? (SPAN + 1) * (SPAN + 1) : 0, CG = CS / 4;
+  static constexpr int NTAPS1 = SEG1 ? (TSPAN + 1) * (TSPAN + 1) : 0, NCH1 = (NTAPS1 + 3) / 4;
+  static constexpr int NCH0 = NTAPS0 * CG, NCH = NCH0 + NCH1;
   static constexpr int NGRP = (NCH + GC - 1) / GC;
   static constexpr int HH = C3_TH + SPAN, HW = C3_TW + SPAN;
   static constexpr int PP = CS * 16 + 16;
   static constexpr int RP = (HW * PP + 255) / 256 * 256;
-  static constexpr int HALO0 = HH * RP;
-  static constexpr int HH1 = 2 * (C3_TH - 1) + 3, HW1 = 2 * (C3_TW - 1) + 3;  // 3x3 stride-2 taps: 17 x 33 source pixels
+  static constexpr int HALO0 = SEG0 ? HH * RP : 0;
+  static constexpr int HH1 = TSTR * (C3_TH - 1) + TSPAN + 1, HW1 = TSTR * (C3_TW - 1) + TSPAN + 1;
   static constexpr int RP1 = HW1 * 16;
   static constexpr int HALO1 = SEG1 ? HH1 * RP1 : 0;
   static constexpr int WSLOT = GC * BN * 64;
@@ -64,24 +69,26 @@ struct Conv3Cfg {
 };
 
 // PRO = 0 none, 1 BN+ReLU, 2 effective gradient (16-bit form: q, r only).
-template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC, int EPI, int PRO>
+template <typename T, int CS, int SPAN, int TSPAN, int TSTR, int NT, int GC, int EPI, int PRO>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   static_assert(sizeof(T) == 2 && CS % 4 == 0, "16-bit storage, whole 64-byte chunks");
   typedef typename TT<T>::vec V;
-  typedef Conv3Cfg<T, CS, SPAN, SEG1, NT, GC> SM;
+  typedef Conv3Cfg<T, CS, SPAN, TSPAN, TSTR, NT, GC> SM;
+  constexpr bool SEG0 = SM::SEG0, SEG1 = SM::SEG1;
   constexpr int SLOT = 8, BN = SM::BN, CG = SM::CG, NCH0 = SM::NCH0, NCH = SM::NCH, NGRP = SM::NGRP;
   constexpr int PP = SM::PP, RP = SM::RP, RP1 = SM::RP1, HH = SM::HH, HW = SM::HW;
-  constexpr int NSL = HH * HW * CS;                    // halo slots of segment 0 per tile
-  constexpr int NI = (NSL + NTHREADS - 1) / NTHREADS;  // per thread
-  constexpr int PSTEP = NTHREADS / CS;                 // halo pixels between a thread's consecutive slots
+  constexpr int CSD = SEG0 ? CS : 1;                   // (divisor that stays legal without a wide segment)
+  constexpr int NSL = SEG0 ? HH * HW * CS : 0;         // halo slots of the wide segment per tile
+  constexpr int NI = SEG0 ? (NSL + NTHREADS - 1) / NTHREADS : 1;  // per thread
+  constexpr int PSTEP = NTHREADS / CSD;                // halo pixels between a thread's consecutive slots
   constexpr int NSL1 = SM::HH1 * SM::HW1;
   constexpr int NI1 = SEG1 ? (NSL1 + NTHREADS - 1) / NTHREADS : 0;
   constexpr int PPC = BN / 16;                         // 1-KiB weight pieces per chunk
   constexpr int NPW = (GC * PPC) / 4;                  // ... per wave and ring slot
-  static_assert((GC * BN) % 64 == 0 && NTHREADS % CS == 0, "weight pieces must split evenly over the waves");
+  static_assert((GC * BN) % 64 == 0 && NTHREADS % CSD == 0, "weight pieces must split evenly over the waves");
   const ConvArgs& a = g.c;
   const Seg& sg = a.seg[0];
-  const Seg& sg1 = a.seg[SEG1 ? 1 : 0];
+  const Seg& sg1 = a.seg[(SEG0 && SEG1) ? 1 : 0];  // the thin segment
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo = smem;
@@ -129,17 +136,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   if (NGRP > 1) issue_w(1);
 
   // ---- halo: every slot loaded once, all loads in flight together ----
-  const int cs = tid % CS, hp0 = tid / CS;
+  const int cs = tid % CSD, hp0 = tid / CSD;
   SlotK<SLOT> kk, kk1;
   kk.k0 = 0.f; kk.k1 = 0.f; kk.k2 = 0.f; kk.k3 = 0.f;
   kk1 = kk;
-  if (PRO == 1) { kk.k0 = load_fv<SLOT>(sg.scale + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.shift + cs * SLOT); }
-  if (PRO == 2) { kk.k0 = load_fv<SLOT>(sg.q + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.r + cs * SLOT); }
+  if (SEG0 && PRO == 1) { kk.k0 = load_fv<SLOT>(sg.scale + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.shift + cs * SLOT); }
+  if (SEG0 && PRO == 2) { kk.k0 = load_fv<SLOT>(sg.q + cs * SLOT); kk.k1 = load_fv<SLOT>(sg.r + cs * SLOT); }
   if (SEG1 && PRO == 1) { kk1.k0 = load_fv<SLOT>(sg1.scale); kk1.k1 = load_fv<SLOT>(sg1.shift); }
   V raw[NI], raw2[PRO == 2 ? NI : 1], rawb[SEG1 ? NI1 : 1];
   bool ok[NI], okb[SEG1 ? NI1 : 1];
   const T* src = (const T*)sg.src + cs * SLOT;
   const T* src2 = (const T*)sg.src2 + cs * SLOT;
+  if constexpr (SEG0)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int hp = hp0 + PSTEP * i;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     for (int i = 0; i < NI1; ++i) {
       const int hp = tid + NTHREADS * i;
       const int hy = hp / SM::HW1, hx = hp - hy * SM::HW1;
-      const int sy = 2 * y0 + g.dymin1 + hy, sx = 2 * x0 + g.dxmin1 + hx;
+      const int sy = TSTR * y0 + g.dymin1 + hy, sx = TSTR * x0 + g.dxmin1 + hx;
       okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
       const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
       const size_t pix = (g.dbg & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
@@ -197,6 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   V z;
 #pragma unroll
   for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+  if constexpr (SEG0)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int hp = hp0 + PSTEP * i;
@@ -234,25 +243,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   const int bsw = (r >> 2) & 3;
   // tap offsets: scalar loads from the kernel arguments, all before the loop - no compiler-counted memory operation may sit
   // between the DMA issue and the counted wait, or hipcc's wait for it drains the DMA as well
-  int toffs[SM::NTAPS0];
+  int toffs[SEG0 ? SM::NTAPS0 : 1];
+  if constexpr (SEG0)
 #pragma unroll
   for (int tap = 0; tap < SM::NTAPS0; ++tap) {
     const int tw = sg.taps[tap];
     toffs[tap] = (int)(signed char)(tw & 0xff) * RP + (int)(signed char)((tw >> 8) & 0xff) * PP;
   }
-  // segment 1: one 16-byte slot per tap; k-step (chunk c, half s) of lane half h reads tap j = 4c + 2s + h (j >= 9: zeros)
-  int off1[SEG1 ? 6 : 1];
+  // thin segment: one 16-byte slot per tap; k-step (chunk c, half s) of lane half h reads tap j = 4c + 2s + h (j >= taps: zeros)
+  constexpr int NT1 = SM::NTAPS1;
+  int off1[SEG1 ? 2 * SM::NCH1 : 1];
   if constexpr (SEG1) {
-    const int abase1 = (2 * ty - g.dymin1) * RP1 + (2 * tx - g.dxmin1) * 16;
+    const int abase1 = (TSTR * ty - g.dymin1) * RP1 + (TSTR * tx - g.dxmin1) * 16;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < SM::NCH1; ++c)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int j0 = 4 * c + 2 * s;  // tap of lane half 0; half 1 reads j0 + 1
-        const int t0 = sg1.taps[j0 < 9 ? j0 : 0], t1 = sg1.taps[j0 + 1 < 9 ? j0 + 1 : 0];
+        const int t0 = sg1.taps[j0 < NT1 ? j0 : 0], t1 = sg1.taps[j0 + 1 < NT1 ? j0 + 1 : 0];
         const int o0 = (int)(signed char)(t0 & 0xff) * RP1 + (int)(signed char)((t0 >> 8) & 0xff) * 16;
         const int o1 = (int)(signed char)(t1 & 0xff) * RP1 + (int)(signed char)((t1 >> 8) & 0xff) * 16;
-        off1[2 * c + s] = (j0 + h < 9) ? abase1 + (h ? o1 : o0) : -1;
+        off1[2 * c + s] = (j0 + h < NT1) ? abase1 + (h ? o1 : o0) : -1;
       }
   }
 
@@ -268,9 +279,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             V av = z;
-            if (ck < NCH0) {
-              av = *(const V*)(halo + abase + toffs[ck / CG] + (ck % CG) * 64 + s * 32);
-            } else if constexpr (SEG1) {
+            if constexpr (SEG0) {
+              if (ck < NCH0) av = *(const V*)(halo + abase + toffs[ck / (SEG0 ? CG : 1)] + (ck % (SEG0 ? CG : 1)) * 64 + s * 32);
+            }
+            if constexpr (SEG1) if (ck >= NCH0) {
               const int o = off1[2 * (ck - NCH0) + s];
               const V ld = *(const V*)(halo1 + (o >= 0 ? o : 0));
               av = o >= 0 ? ld : z;
@@ -395,11 +407,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 static bool g_conv3 = getenv("DMM_NO_CONV3") == nullptr;
 void conv3_set_enabled(bool on) { g_conv3 = on; }
 
-template <typename T, int CS, int SPAN, bool SEG1, int NT, int GC, int EPI, int PRO>
+template <typename T, int CS, int SPAN, int TSPAN, int TSTR, int NT, int GC, int EPI, int PRO>
 static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
-  typedef Conv3Cfg<T, CS, SPAN, SEG1, NT, GC> SM;
+  typedef Conv3Cfg<T, CS, SPAN, TSPAN, TSTR, NT, GC> SM;
   static_assert(SM::bytes <= 80 * 1024, "two workgroups per CU");
-  auto kern = conv3_kernel<T, CS, SPAN, SEG1, NT, GC, EPI, PRO>;
+  auto kern = conv3_kernel<T, CS, SPAN, TSPAN, TSTR, NT, GC, EPI, PRO>;
   static bool attr_done = false;
   if (SM::bytes > 48 * 1024 && !attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM::bytes);
@@ -411,19 +423,23 @@ static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
 }
 
 template <typename T>
-static hipError_t launch_c3_type(const Conv3Args& g, int epi, int pro, int cs, int span, bool seg1, int nt, hipStream_t st) {
+static hipError_t launch_c3_type(const Conv3Args& g, int epi, int pro, int cs, int span, int tspan, int tstr, int nt, hipStream_t st) {
   if (epi == EPI_STORE && pro == 1) {
-    if (!seg1 && span == 2 && nt == 1 && cs == 16) return launch_c3<T, 16, 2, false, 1, 4, EPI_STORE, 1>(g, st);  // dense conv2
-    if (!seg1 && span == 2 && nt == 1 && cs == 8) return launch_c3<T, 8, 2, false, 1, 2, EPI_STORE, 1>(g, st);
-    if (seg1 && span == 1 && nt == 2 && cs == 16) return launch_c3<T, 16, 1, true, 2, 2, EPI_STORE, 1>(g, st);    // refine0 phase
+    if (tspan < 0 && span == 2 && nt == 1 && cs == 16) return launch_c3<T, 16, 2, -1, 1, 1, 4, EPI_STORE, 1>(g, st);  // dense conv2
+    if (tspan < 0 && span == 2 && nt == 1 && cs == 8) return launch_c3<T, 8, 2, -1, 1, 1, 2, EPI_STORE, 1>(g, st);
+    if (tspan == 2 && tstr == 2 && span == 1 && nt == 2 && cs == 16) return launch_c3<T, 16, 1, 2, 2, 2, 2, EPI_STORE, 1>(g, st);  // refine0 phase
   }
-  if (epi == EPI_BNBWD && !seg1 && span == 2) {
-    if (cs == 4 && nt == 4 && pro == 2) return launch_c3<T, 4, 2, false, 4, 1, EPI_BNBWD, 2>(g, st);              // dense conv2 dgrad
-    if (cs == 4 && nt == 4 && pro == 0) return launch_c3<T, 4, 2, false, 4, 1, EPI_BNBWD, 0>(g, st);
-    if (cs == 4 && nt == 2 && pro == 2) return launch_c3<T, 4, 2, false, 2, 1, EPI_BNBWD, 2>(g, st);
-    if (cs == 4 && nt == 2 && pro == 0) return launch_c3<T, 4, 2, false, 2, 1, EPI_BNBWD, 0>(g, st);
-    if (cs == 8 && nt == 1 && pro == 0) return launch_c3<T, 8, 2, false, 1, 2, EPI_BNBWD, 0>(g, st);              // refine0 -> raw input
-    if (cs == 8 && nt == 1 && pro == 2) return launch_c3<T, 8, 2, false, 1, 2, EPI_BNBWD, 2>(g, st);
+  if (epi == EPI_BNBWD && tspan < 0 && span == 2) {
+    if (cs == 4 && nt == 4 && pro == 2) return launch_c3<T, 4, 2, -1, 1, 4, 1, EPI_BNBWD, 2>(g, st);              // dense conv2 dgrad
+    if (cs == 4 && nt == 4 && pro == 0) return launch_c3<T, 4, 2, -1, 1, 4, 1, EPI_BNBWD, 0>(g, st);
+    if (cs == 4 && nt == 2 && pro == 2) return launch_c3<T, 4, 2, -1, 1, 2, 1, EPI_BNBWD, 2>(g, st);
+    if (cs == 4 && nt == 2 && pro == 0) return launch_c3<T, 4, 2, -1, 1, 2, 1, EPI_BNBWD, 0>(g, st);
+    if (cs == 8 && nt == 1 && pro == 0) return launch_c3<T, 8, 2, -1, 1, 1, 2, EPI_BNBWD, 0>(g, st);              // refine0 -> raw input
+    if (cs == 8 && nt == 1 && pro == 2) return launch_c3<T, 8, 2, -1, 1, 1, 2, EPI_BNBWD, 2>(g, st);
+  }
+  if (epi == EPI_BNBWD && cs == 0 && tspan == 4 && tstr == 1 && pro == 0) {                                          // refine1 dgrad (5x5)
+    if (nt == 2) return launch_c3<T, 0, 0, 4, 1, 2, 2, EPI_BNBWD, 0>(g, st);
+    if (nt == 1) return launch_c3<T, 0, 0, 4, 1, 1, 2, EPI_BNBWD, 0>(g, st);
   }
   return hipErrorNotSupported;
 }
@@ -437,8 +453,8 @@ static bool tap_box(const Seg& sg, int& dymin, int& dxmin, int& span) {
     dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
   }
   span = dymax - dymin;
-  if (span < 0 || span > 3 || dxmax - dxmin != span || sg.ntaps != (span + 1) * (span + 1)) return false;
-  bool seen[16] = {false};
+  if (span < 0 || span > 4 || dxmax - dxmin != span || sg.ntaps != (span + 1) * (span + 1)) return false;
+  bool seen[25] = {false};
   for (int t = 0; t < sg.ntaps; ++t) {  // every offset of the box exactly once, in any order
     const int dy = (int)(signed char)(sg.taps[t] & 0xff) - dymin, dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff) - dxmin;
     if (seen[dy * (span + 1) + dx]) return false;
@@ -452,32 +468,38 @@ static bool tap_box(const Seg& sg, int& dymin, int& dxmin, int& span) {
 hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (!g_conv3 || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2 || a.pool2 || (epi != EPI_STORE && epi != EPI_BNBWD)) return hipErrorNotSupported;
   const Seg& sg = a.seg[0];
-  if (sg.mode != G_PLAIN || sg.istride != 1 || sg.C % 32 || sg.Cpad != sg.C || sg.Hs != a.Ho || sg.Ws != a.Wo) return hipErrorNotSupported;
   if (a.Npad % 32 || a.Npad > 128) return hipErrorNotSupported;
   Conv3Args g;
   g.c = a;
-  int span = 0, span1 = 0;
-  g.dymin1 = g.dxmin1 = 0;
-  if (!tap_box(sg, g.dymin0, g.dxmin0, span) || span < 1 || span > 2) return hipErrorNotSupported;
-  const bool seg1 = a.nseg == 2;
-  if (seg1) {
-    const Seg& s1 = a.seg[1];
-    if (s1.mode != G_PLAIN || s1.istride != 2 || s1.C != 8 || s1.Cpad != 8 || s1.ntaps != 9 || s1.Hs != 2 * a.Ho || s1.Ws != 2 * a.Wo ||
-        (s1.scale != nullptr) != (sg.scale != nullptr) || s1.q != nullptr)
-      return hipErrorNotSupported;
-    if (!tap_box(s1, g.dymin1, g.dxmin1, span1) || span1 != 2) return hipErrorNotSupported;
-  } else if (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo) {
-    return hipErrorNotSupported;
+  g.dymin0 = g.dxmin0 = g.dymin1 = g.dxmin1 = 0;
+  int cs = 0, span = 0, tspan = -1, tstr = 1;
+  auto thin_ok = [&](const Seg& s1, int stride) {
+    return s1.mode == G_PLAIN && s1.istride == stride && s1.C == 8 && s1.Cpad == 8 && s1.Hs == stride * a.Ho && s1.Ws == stride * a.Wo &&
+           s1.q == nullptr && tap_box(s1, g.dymin1, g.dxmin1, tspan);
+  };
+  if (a.nseg == 1 && sg.C == 8) {   // thin segment only: the logits gradient under the 5x5 head convolution
+    if (!thin_ok(sg, 1) || tspan != 4 || sg.scale != nullptr) return hipErrorNotSupported;
+  } else {
+    if (sg.mode != G_PLAIN || sg.istride != 1 || sg.C % 32 || sg.Cpad != sg.C || sg.Hs != a.Ho || sg.Ws != a.Wo) return hipErrorNotSupported;
+    if (!tap_box(sg, g.dymin0, g.dxmin0, span) || span < 1 || span > 2) return hipErrorNotSupported;
+    cs = sg.C / 8;
+    if (a.nseg == 2) {
+      tstr = 2;
+      if (!thin_ok(a.seg[1], 2) || tspan != 2 || (a.seg[1].scale != nullptr) != (sg.scale != nullptr)) return hipErrorNotSupported;
+    }
   }
+  if (a.nseg == 1 && (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo)) return hipErrorNotSupported;
   const int pro = sg.scale ? 1 : (sg.q ? 2 : 0);
   if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
   g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
   g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
   static const int dbg = getenv("DMM_C3_DBG") ? atoi(getenv("DMM_C3_DBG")) : 0;
   g.dbg = dbg;
-  const int cs = sg.C / 8, nt = a.Npad / 32;
-  return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, seg1, nt, st)
-                         : launch_c3_type<bf16>(g, epi, pro, cs, span, seg1, nt, st);
+  const int nt = a.Npad / 32;
+  static const bool trace = getenv("DMM_C3_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);
+  return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, tspan, tstr, nt, st)
+                         : launch_c3_type<bf16>(g, epi, pro, cs, span, tspan, tstr, nt, st);
 }
 
 }  // namespace dmm
