@@ -426,9 +426,15 @@ template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
 extern template hipError_t launch_wt<float>(const WgradArgs&, bool, hipStream_t);
 extern template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
 
+hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st);  // wg3.hip
+
 // Fills rows_per_split / kgroups (if zero) and launches.
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
+  if (mfma) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
+    const hipError_t e = launch_wg3(a, dtype, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const int BK = dtype == DT_F32 ? 16 : 32;
   const int bmw = dtype == DT_F32 ? 32 : 64;
   int total = 0;
