@@ -407,10 +407,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 static bool g_conv3 = getenv("DMM_NO_CONV3") == nullptr;
 void conv3_set_enabled(bool on) { g_conv3 = on; }
 
+static thread_local bool g_c3_dry = false;  // conv3_handles(): walk the dispatch without launching
+
 template <typename T, int CS, int SPAN, int TSPAN, int TSTR, int NT, int GC, int EPI, int PRO>
 static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
   typedef Conv3Cfg<T, CS, SPAN, TSPAN, TSTR, NT, GC> SM;
   static_assert(SM::bytes <= 80 * 1024, "two workgroups per CU");
+  if (g_c3_dry) return hipSuccess;
   auto kern = conv3_kernel<T, CS, SPAN, TSPAN, TSTR, NT, GC, EPI, PRO>;
   static bool attr_done = false;
   if (SM::bytes > 48 * 1024 && !attr_done) {
@@ -500,6 +503,14 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (trace) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);
   return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, tspan, tstr, nt, st)
                          : launch_c3_type<bf16>(g, epi, pro, cs, span, tspan, tstr, nt, st);
+}
+
+// Does launch_conv3 take this launch?  (the plan labels its launches by the kernel family that runs them)
+bool conv3_handles(const ConvArgs& a, int dtype, int epi) {
+  g_c3_dry = true;
+  const hipError_t e = launch_conv3(a, dtype, epi, nullptr);
+  g_c3_dry = false;
+  return e == hipSuccess;
 }
 
 }  // namespace dmm

@@ -571,14 +571,17 @@ static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
 
 template <typename T, int EPI>
 static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
-  if (EPI == EPI_BNBWD) {  // wide outputs take 128-column tiles: half as many re-gathers of the gradient operand
-    if (a.Npad % 128 == 0) return launch_bn<T, 128, EPI>(a, mfma, st);
-    if (a.Npad % 64 == 0) return launch_bn<T, 64, EPI>(a, mfma, st);
-    return launch_bn<T, 32, EPI>(a, mfma, st);
-  }
   if (EPI == EPI_LOGITS) return launch_bn<T, 32, EPI>(a, mfma, st);
-  if (a.Npad % 128 == 0) return launch_bn<T, 128, EPI>(a, mfma, st);
-  if (a.Npad % 64 == 0) return launch_bn<T, 64, EPI>(a, mfma, st);
+  // Column tile: as wide as the padded output allows (128-column tiles re-gather the A operand half as often as 64-column
+  // ones).  Narrower tiles for launches with few workgroups (DMM_MIN_WGS = n: halve the tile until the launch has n workgroups)
+  // were measured on C2 b4 and do NOT help the small maps of blocks 3-4 / decoder stages 1-2 (33.57 ms/step at 0, 33.45 at 300,
+  // 33.71 at 400, 34.13 at 1000): their cost is the length of each workgroup's chain of dependent stages, not idle CUs.
+  static const int min_wgs = getenv("DMM_MIN_WGS") ? atoi(getenv("DMM_MIN_WGS")) : 0;
+  const int mtiles = (a.M + BM - 1) / BM;
+  int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
+  while (bn > 32 && mtiles * (a.Npad / bn) < min_wgs) bn >>= 1;
+  if (bn == 128) return launch_bn<T, 128, EPI>(a, mfma, st);
+  if (bn == 64) return launch_bn<T, 64, EPI>(a, mfma, st);
   return launch_bn<T, 32, EPI>(a, mfma, st);
 }
 

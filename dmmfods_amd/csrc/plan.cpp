@@ -532,7 +532,8 @@ struct Builder {
       {
         char cb[32];
         const double np = (double)c.phases.size();
-        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : "igemm.store", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        const bool c3 = d.use_mfma && conv3_handles(a, dtype, c.epi);
+        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : (c3 ? "conv3.store" : "igemm.store"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + out_bytes(c)) / np + w_bytes(c) / np);
       }
       if (c.epi == EPI_LOGITS) {
@@ -611,7 +612,7 @@ struct Builder {
       a.N = c.seg[0].C; a.Npad = pd.Npad;
       a.dpack = (float*)pd.dpack;
       char cb[32];
-      tag(o, ncls("wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
+      tag(o, ncls((d.use_mfma && wg3_handles(a, dtype)) ? "wg3" : "wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
           src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
     } else
     for (auto& ph : c.phases) {
@@ -679,7 +680,7 @@ struct Builder {
         // reads: output gradient (+ forward output for the correction), x for the ReLU mask, (old gradient); writes gradient
         const double srcb = (double)sb.B * sb.H * sb.W * sr.C * esz;
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
-        tag(o, ncls("igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
+        tag(o, ncls((d.use_mfma && conv3_handles(a, dtype, EPI_BNBWD)) ? "conv3.bnbwd" : "igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
       if (!raw) sb.ginit = true;

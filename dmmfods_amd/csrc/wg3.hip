@@ -178,8 +178,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void wg3_kernel(const Wg3Args g) {
 static bool g_wg3 = getenv("DMM_NO_WG3") == nullptr;
 void wg3_set_enabled(bool on) { g_wg3 = on; }
 
+static thread_local bool g_wg3_dry = false;
+
 template <typename T, int PQ>
 static hipError_t launch_wg3_t(const Wg3Args& g, int nwg, hipStream_t st) {
+  if (g_wg3_dry) return hipSuccess;
   auto kern = wg3_kernel<T, PQ>;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), W3_LDS, st, g);
   return hipGetLastError();
@@ -208,6 +211,7 @@ hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
   g.tiles_x = (a.Wo + W3_TW - 1) / W3_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
   // time ~ tiles/nwg * t_tile + nwg * (147 KB of fp32 atomics at the chip-wide atomic rate): minimum at nwg ~ sqrt(14 * tiles)
+  if (g_wg3_dry) return hipSuccess;
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   int nwg = (int)std::lround(std::sqrt(14.0 * g.ntiles));
@@ -217,6 +221,13 @@ hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
   const int pq = q.q ? 2 : 0;
   if (dtype == DT_F16) return pq ? launch_wg3_t<f16, 2>(g, nwg, st) : launch_wg3_t<f16, 0>(g, nwg, st);
   return pq ? launch_wg3_t<bf16, 2>(g, nwg, st) : launch_wg3_t<bf16, 0>(g, nwg, st);
+}
+
+bool wg3_handles(const WgradArgs& a, int dtype) {
+  g_wg3_dry = true;
+  const hipError_t e = launch_wg3(a, dtype, nullptr);
+  g_wg3_dry = false;
+  return e == hipSuccess;
 }
 
 }  // namespace dmm
