@@ -63,7 +63,12 @@ def synthetic_batch(c, device, seed):
     return rgb, lidar, tgt
 
 
-def collect_profile(model, plan, K, ops_out=None):
+ENC_1X1 = __import__("re").compile(r"/(f|s2)\.(b\d+\.l\d+\.conv1|transition\d+\.conv)$|/concat_module\.conv$")
+
+
+def collect_profile(model, plan, K, ops_out=None, enc=None):
+    """Per-class sums of the per-launch event times; `enc` (a dict) receives the forward time / FLOPs of the DenseNet encoder's
+    1x1 convolutions (dense-layer bottlenecks, transitions, the fusion module): north_star's MFMA target is quoted on them."""
     from dmmfods_amd import _lib
     L = _lib.lib()
     classes = {}
@@ -78,6 +83,9 @@ def collect_profile(model, plan, K, ops_out=None):
             label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
             L.dmm_plan_profile_op(plan.handle, which, i, C.byref(label), C.byref(fl), C.byref(by))
             cls = (label.value or b"").decode().split("/")[0] or "other"
+            if enc is not None and which == 0 and ENC_1X1.search((label.value or b"").decode()):
+                enc["ms"] = enc.get("ms", 0.0) + ms[i] / passes.value
+                enc["flops"] = enc.get("flops", 0.0) + fl.value
             if ops_out is not None and ms[i] > 0:
                 ops_out.append((ms[i] / passes.value, (label.value or b"").decode(), fl.value, by.value))
             e = classes.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
@@ -256,7 +264,8 @@ def main():
         step()
         torch.cuda.synchronize()
         ops_list = [] if args.ops else None
-        full_classes = collect_profile(model, plan, 1, ops_list)
+        enc = {}
+        full_classes = collect_profile(model, plan, 1, ops_list, enc)
         if full_classes and rank == 0:
             dom = max(full_classes.items(), key=lambda kv: kv[1]["ms"])[0]
             dom_prefix = (dom + "/").encode()
@@ -311,6 +320,11 @@ def main():
             "mfma_only_frac_of_step": round(3 * fwd_flops_img * value / 1e12 / (world * PEAK_MFMA_TFLOPS[c["dtype"]]), 4),
             "roofline": roof,
         }
+        if not args.no_profile and full_classes and enc.get("ms"):
+            # forward time of the encoder's 1x1 convolutions in the serial per-launch pass vs the dense MFMA peak
+            out["encoder_1x1"] = {"fwd_ms": round(enc["ms"], 3), "fwd_gflop": round(enc["flops"] / 1e9, 1),
+                                  "tflops": round(enc["flops"] / enc["ms"] / 1e9, 1),
+                                  "mfma_frac": round(enc["flops"] / enc["ms"] / 1e9 / PEAK_MFMA_TFLOPS[c["dtype"]], 4)}
         if table and args.table:
             for r in table:
                 print(json.dumps(r), file=sys.stderr)

@@ -16,13 +16,19 @@ EPI = {"0": "store", "1": "bnbwd", "2": "logits"}
 
 
 def classify(name):
-    m = re.search(r"igemm_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)E", name)
+    m = re.search(r"igemm_kernelI(?:DF16_|DF16b|f)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"igemm.{EPI.get(m.group(2), m.group(2))}.n{m.group(1)}"
+    # conv3_kernel<T, CS, SPAN, TSPAN, TSTR, NT, GC, EPI, PRO>
+    m = re.search(r"conv3_kernelI(?:DF16_|DF16b)Li\d+ELi\d+ELin?\d+ELi\d+ELi(\d+)ELi\d+ELi(\d+)ELi\d+E", name)
+    if m:
+        return f"conv3.{EPI.get(m.group(2), m.group(2))}.n{32 * int(m.group(1))}"
+    if "wg3_kernel" in name:
+        return "wg3.n128"
     m = re.search(r"halo_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"igemm.{EPI.get(m.group(2), m.group(2))}.n{m.group(1)}"
-    m = re.search(r"wgrad_kernelI(?:DF16_|f)Li(\d+)E", name)
+    m = re.search(r"wgrad_kernelI(?:DF16_|DF16b|f)Li(\d+)E", name)
     if m:
         return f"wgrad*.n{m.group(1)}"
     m = re.search(r"dmm(?:::|\d+)(\w+?)_kernel", name)
