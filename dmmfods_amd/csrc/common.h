@@ -36,7 +36,10 @@ template <> struct TT<bf16> {
 };
 
 constexpr int MAX_TAPS = 52;
-constexpr int STAT_REPS = 8;   // replicas of the BatchNorm reduction accumulators (one per XCD)
+#ifndef DMM_STAT_REPS
+#define DMM_STAT_REPS 8
+#endif
+constexpr int STAT_REPS = DMM_STAT_REPS;  // replicas of the BatchNorm reduction accumulators (low 3 bits of the workgroup id = XCD)
 constexpr int BM = 128;        // rows (pixels) per workgroup tile
 constexpr int NTHREADS = 256;  // 4 waves of 64
 constexpr int ROWB = 64;       // LDS bytes per tile row = one K-chunk; the four 16-byte slots of a row are XOR-swizzled

@@ -266,7 +266,11 @@ __device__ __forceinline__ typename TT<T>::vec gather_finish(const Seg& sg, cons
       for (int i = 0; i < S; ++i) f[i] = (f[i] + fmaf(k.k1[i], f2[i], k.k0[i])) + fmaf(k.k3[i], f2[i], k.k2[i]);
       out = f32_to_vec<T>(f);
     }
-    return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
+    typename TT<T>::vec zero;
+#pragma unroll
+  for (int e = 0; e < TT<T>::SLOT; ++e) zero[e] = (T)0;
+  // state 0: r.v holds zeros; 2: already final; 3: loaded from a clamped address to keep the load count constant -> zeros
+  return r.state == 1 ? out : (r.state == 3 ? zero : r.v);
   }
   if (r.state != 1) return r.v;  // zero or already final
   if (sg.scale != nullptr) {
@@ -378,7 +382,11 @@ __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSl
   typename TT<T>::vec out = r.v;
   if (PRO == 1 || (PRO < 0 && narr == 2)) out = bn_relu_slot(r.v, k);
   if (PRO == 2 || (PRO < 0 && narr == 4)) out = eff_grad_slot(r.v, r.v2, k);
-  return r.state == 1 ? out : r.v;  // state 0: r.v holds zeros; state 2: already final
+  typename TT<T>::vec zero;
+#pragma unroll
+  for (int e = 0; e < TT<T>::SLOT; ++e) zero[e] = (T)0;
+  // state 0: r.v holds zeros; 2: already final; 3: loaded from a clamped address to keep the load count constant -> zeros
+  return r.state == 1 ? out : (r.state == 3 ? zero : r.v);
 }
 
 // Decompose a row index into (b, y, x) of the row grid.

@@ -42,6 +42,15 @@ template <> struct Mma<float> {
 #define IGEMM_KS128 2
 #endif
 constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
+#ifndef IGEMM_FAT
+#define IGEMM_FAT 0  // instantiate the 8-wave variants (measured: no gain)
+#endif
+#ifndef IGEMM_EPI_EARLY
+#define IGEMM_EPI_EARLY 0
+#endif
+#ifndef IGEMM_ASM_DMA
+#define IGEMM_ASM_DMA 0
+#endif
 #ifndef IGEMM_ADIST
 #define IGEMM_ADIST 1
 #endif
@@ -93,17 +102,22 @@ __device__ __forceinline__ SegU seg_uniform(const Seg& sg) {
   return r;
 }
 
-template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO, int KSV>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
+// NW = waves per workgroup.  8 ("fat"): two groups of four waves share the tile, each group takes half of the K chunks of a
+// stage (KSV counts the chunks of BOTH groups) and the accumulators are added through LDS in front of the epilogue: twice the
+// waves and half the chain of dependent stages for launches that have fewer workgroups than the chip has slots.
+template <typename T, int BN, int EPI, bool MFMA, bool LIN, int PRO, int KSV, int NW>
+__global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
+  constexpr int NTHREADS = 64 * NW;  // (shadows the 4-wave constant of common.h)
+  constexpr int NG = NW / 4;         // wave groups
   constexpr int SLOT = TT<T>::SLOT;
   constexpr int BK = 4 * SLOT;
   typedef typename TT<T>::vec V;
   typedef IgemmSmem<T, BN, KSV> SM;
   constexpr int NT = BN / 32;
   constexpr int KS = KSV;
-  constexpr int NB = KS * BN / 64;  // 1-KiB LDS-DMA pieces of the B image per wave per stage
-  constexpr int NR = 2 * KS;        // rows per thread
-  constexpr int RST = 64 / KS;      // row groups; a thread owns rows rg + RST i
+  constexpr int NB = KS * BN / (16 * NW);  // 1-KiB LDS-DMA pieces of the B image per wave per stage
+  constexpr int RST = NTHREADS / KS / 4;   // row groups; a thread owns rows rg + RST i
+  constexpr int NR = BM / RST;             // rows per thread
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAINB = (SM::MAIN > (EPI == EPI_STORE ? SM::STAGE_T : SM::STAGE_F)) ? SM::MAIN
@@ -209,36 +223,57 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     int s, c, narr;
   };
   ARing R0, R1;
+  const unsigned bdst0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + SM::A_BYTES + wave * NB * 1024);
   auto issue_b = [&](int buf, int stage) {  // weights: LDS-DMA (a dead chunk re-reads chunk 0: its A slots are zero)
     const int g = stage * KS + ub;
     const T* bsrc = wp + (size_t)(g < total ? g : 0) * a.Npad * BK;
+#if IGEMM_ASM_DMA
+    // Inline-assembly form of the weight DMA: the compiler does not see it, so it does not drain vmcnt to 0 in front of the
+    // LDS reads (it does for the builtin) and the gathered operand's loads of the NEXT stage stay in flight (ADIST = 2).  The DMA
+    // of stage s is older than the A loads issued after it; the compiler's counted wait in the next store_a leaves at most those
+    // newer loads outstanding, so this DMA has landed before the barrier in front of mma(s).
+    const unsigned dst = bdst0 + buf * (SM::A_BYTES + SM::B_BYTES);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      unsigned keep;
+      if (!(IGEMM_DBG & 8))
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(bsrc + boff[q]), "s"(dst + q * 1024) : "memory");
+    }
+#else
     unsigned char* Bs = smem + buf * (SM::A_BYTES + SM::B_BYTES) + SM::A_BYTES + wave * NB * 1024;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
       if (!(IGEMM_DBG & 8)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + boff[q]),
                                        (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
+#endif
   };
   auto issue_a = [&](ARing& R, int stage) {
     RawSlot<T>(&araw)[NR] = R.raw;
     const int g = stage * KS + u;
     const bool live = g < total;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-#pragma unroll
-      for (int e = 0; e < SLOT; ++e) { araw[i].v[e] = (T)0; araw[i].v2[e] = (T)0; }
-      araw[i].state = 0;
-    }
-    if constexpr (LIN) {
-      const int c = g * BK + j * SLOT;
-      const bool cv = live && c < su0.C;
-      R.s = 0; R.c = c; R.narr = cv ? su0.narr : 0;
+    if constexpr (!LIN) {
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        if (cv && rv[i]) {
-          if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su0.src + roff[i] + c);
-          if (!(IGEMM_DBG & 1) && (PRO == 2 || (PRO < 0 && su0.narr == 4))) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + c);
-          araw[i].state = 1;
-        }
+#pragma unroll
+        for (int e = 0; e < SLOT; ++e) { araw[i].v[e] = (T)0; araw[i].v2[e] = (T)0; }
+        araw[i].state = 0;
+      }
+    }
+    if constexpr (LIN) {
+      // branch-free: every thread issues every load of every stage (addresses clamped to a valid slot, the result dropped by
+      // `state`), so that the number of loads in flight behind a given one is a compile-time constant and the compiler's
+      // counted s_waitcnt in store_a leaves the next stage's loads in flight
+      const int c = g * BK + j * SLOT;
+      const bool cv = live && c < su0.C;
+      const int cc = cv ? c : 0;
+      R.s = 0; R.c = cc; R.narr = cv ? su0.narr : 0;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su0.src + roff[i] + cc);
+        if (!(IGEMM_DBG & 1) && (PRO == 2 || (PRO < 0 && su0.narr == 4))) araw[i].v2 = *(const V*)((const T*)su0.src2 + roff2[i] + cc);
+        araw[i].state = (cv && rv[i]) ? 1 : 3;
       }
       return;
     }
@@ -266,12 +301,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int sy = ry[i] * su.istride + dy, sx = rx[i] * su.istride + dx;
-      if (inside && rv[i] && (unsigned)sy < hl && (unsigned)sx < wl) {
-        const size_t pix = (size_t)((rb[i] * su.Hs + (sy >> up)) * su.Ws + (sx >> up));
-        if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su.src + pix * su.ld + c);
-        if (!(IGEMM_DBG & 1) && two) araw[i].v2 = *(const V*)((const T*)su.src2 + pix * su.ld2 + c);
-        araw[i].state = 1;
-      }
+      const bool ok = inside && rv[i] && (unsigned)sy < hl && (unsigned)sx < wl;
+      const size_t pix = ok ? (size_t)((rb[i] * su.Hs + (sy >> up)) * su.Ws + (sx >> up)) : 0;  // branch-free, as above
+      if (!(IGEMM_DBG & 1)) araw[i].v = *(const V*)((const T*)su.src + pix * su.ld + c);
+      if (!(IGEMM_DBG & 1) && two) araw[i].v2 = *(const V*)((const T*)su.src2 + pix * su.ld2 + c);
+      araw[i].state = ok ? 1 : 3;
     }
   };
   auto store_a = [&](const ARing& R, int buf) {
@@ -295,11 +329,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     const unsigned char* Bs = As + SM::A_BYTES;
     if (MFMA) {
 #pragma unroll
-      for (int uu = 0; uu < KS; ++uu)
+      for (int uq = 0; uq < KS / NG; ++uq)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+          const int uu = (wave >> 2) * (KS / NG) + uq;         // this wave group's chunks of the stage
           const int sw = ((2 * s + h) ^ ((r >> 2) & 3)) << 4;  // BM, BN and 32 are multiples of 16: swizzle depends on r only
-          const V av = *(const V*)(As + (uu * BM + 32 * wave + r) * ROWB + sw);
+          const V av = *(const V*)(As + (uu * BM + 32 * (wave & 3) + r) * ROWB + sw);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const V bv = *(const V*)(Bs + (uu * BN + 32 * t + r) * ROWB + sw);
@@ -328,23 +363,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
     }
   };
 
-  ARing& RA = R0;
-  ARing& RB = ADIST == 2 ? R1 : R0;
-  issue_b(0, 0);
-  issue_a(RA, 0);
-  if (ADIST == 2) issue_a(RB, 1);
-  for (int it = 0; it < nstages; it += 2) {
-    store_a(RA, 0);
-    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
-    issue_b(1, it + 1);
-    if (it + ADIST < nstages) issue_a(RA, it + ADIST);
-    mma(0);
-    store_a(RB, 1);
-    __syncthreads();
-    if (it + 2 < nstages) issue_b(0, it + 2);
-    if (it + 1 + ADIST < nstages) issue_a(RB, it + 1 + ADIST);
-    mma(1);
-  }
   // ---- epilogue geometry: thread = (slot column cv, row phase rr), rows rr + RPP i ----
   constexpr int NCV = BN / SLOT;       // slot columns in the tile
   constexpr int RPP = NTHREADS / NCV;  // rows per pass
@@ -357,7 +375,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
   V xpre[NIT], gpre[NIT];
   int ppre[NIT];
   const bool prefetched = EPI == EPI_BNBWD && !a.pool2;
-  if (EPI == EPI_BNBWD && prefetched) {
+  auto prefetch_epi = [&]() {
+    if (!(EPI == EPI_BNBWD && prefetched)) return;
     const T* bx = (const T*)a.bx;
     const T* g = (const T*)a.out;
 #pragma unroll
@@ -371,29 +390,71 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
         if (a.accumulate && g != nullptr) gpre[i] = *(const V*)(g + (size_t)pix * a.ldo + n);
       }
     }
+  };
+  // a 1x1 data gradient has one or two K stages: its epilogue operands are the bulk of the traffic, so they start first
+  constexpr bool EPI_EARLY = IGEMM_EPI_EARLY && LIN && EPI == EPI_BNBWD;
+  if constexpr (EPI_EARLY) prefetch_epi();
+  ARing& RA = R0;
+  ARing& RB = ADIST == 2 ? R1 : R0;
+  issue_b(0, 0);
+  issue_a(RA, 0);
+  if (ADIST == 2) issue_a(RB, 1);
+  for (int it = 0; it < nstages; it += 2) {
+    store_a(RA, 0);
+    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+    issue_b(1, it + 1);
+    issue_a(RA, it + ADIST);  // past the end: dead stage (clamped loads, dropped)
+    mma(0);
+    store_a(RB, 1);
+    __syncthreads();
+    if (it + 2 < nstages) issue_b(0, it + 2);  // (the staging below reuses the image: no DMA may be left in flight)
+    issue_a(RB, it + 1 + ADIST);
+    mma(1);
+  }
+  if constexpr (!EPI_EARLY) prefetch_epi();
+  if constexpr (NG == 2) {  // add the second wave group's partial sums to the first's
+    __syncthreads();
+    float* Cx = (float*)smem;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * (wave & 3) + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (wave >= 4) Cx[row * SM::STAGE_PITCH_F + 32 * t + r] = acc[t][i];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * (wave & 3) + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (wave < 4) acc[t][i] += Cx[row * SM::STAGE_PITCH_F + 32 * t + r];
+      }
   }
   __syncthreads();  // all waves done with the operand image; reuse it for epilogue staging
   if ((IGEMM_DBG & 4) && acc[0][0] != 123.f) return;
 
   // ---- stage the accumulators through LDS: Cs[row][col] ----
-  if (EPI == EPI_STORE) {
-    T* Cs = (T*)smem;
+  if (wave < 4) {
+    if (EPI == EPI_STORE) {
+      T* Cs = (T*)smem;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-        Cs[row * SM::STAGE_PITCH_T + 32 * t + r] = from_f32<T>(acc[t][i]);
-      }
-  } else {
-    float* Cs = (float*)smem;
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+          Cs[row * SM::STAGE_PITCH_T + 32 * t + r] = from_f32<T>(acc[t][i]);
+        }
+    } else {
+      float* Cs = (float*)smem;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-        Cs[row * SM::STAGE_PITCH_F + 32 * t + r] = acc[t][i];
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+          Cs[row * SM::STAGE_PITCH_F + 32 * t + r] = acc[t][i];
+        }
+    }
   }
   __syncthreads();
 
@@ -519,11 +580,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int EPI, int KSV>
+template <typename T, int BN, int EPI, int KSV, int NW>
 static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
   const int mtiles = (a.M + BM - 1) / BM;
   const int ntiles = a.Npad / BN;
-  dim3 grid(mtiles * ntiles), block(NTHREADS);
+  dim3 grid(mtiles * ntiles), block(64 * NW);
   int kfl = 0;
   for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
   int nchunks = 0;
@@ -545,11 +606,12 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
   if (!mfma) {
     // the scalar check kernels exist for fp32 / f16 (bring-up); bf16 arrived with the MFMA kernels already proven
     if constexpr (std::is_same<T, bf16>::value) return hipErrorNotSupported;
-    else { kern = igemm_kernel<T, BN, EPI, false, false, -1, KSV>; ai = 0; }
+    else if constexpr (NW != 4) return hipErrorNotSupported;
+    else { kern = igemm_kernel<T, BN, EPI, false, false, -1, KSV, NW>; ai = 0; }
   }
-  else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1, KSV> : igemm_kernel<T, BN, EPI, true, false, P1, KSV>; ai = lin ? 1 : 2; }
-  else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0, KSV> : igemm_kernel<T, BN, EPI, true, false, 0, KSV>; ai = lin ? 3 : 4; }
-  else { kern = igemm_kernel<T, BN, EPI, true, false, -1, KSV>; ai = 5; }
+  else if (pro == P1) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, P1, KSV, NW> : igemm_kernel<T, BN, EPI, true, false, P1, KSV, NW>; ai = lin ? 1 : 2; }
+  else if (pro == 0) { kern = lin ? igemm_kernel<T, BN, EPI, true, true, 0, KSV, NW> : igemm_kernel<T, BN, EPI, true, false, 0, KSV, NW>; ai = lin ? 3 : 4; }
+  else { kern = igemm_kernel<T, BN, EPI, true, false, -1, KSV, NW>; ai = 5; }
   static int attr_bytes[6] = {0, 0, 0, 0, 0, 0};
   if (smem > 48 * 1024 && smem > attr_bytes[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -564,9 +626,26 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
 // Chunks per stage: measured on MI355X (C2 b4) - 4 chunks per stage for the launches with <= 512 workgroups (halving their
 // stage chain at 128+ KB of LDS) made the step 1.2 ms slower, 1 chunk per stage for the 128-column variants (a third workgroup
 // per CU) was +-1 %; every variant therefore takes 2 chunks per stage.
+// Measured on MI355X, C2 b4 (round 2), all kept as compile-time knobs and all OFF: (1) IGEMM_ASM_DMA + IGEMM_ADIST = 2 (counted
+// waits, two stages of the gathered operand in flight): store class -4 %, bnbwd class +3 % (264 VGPRs), step 33.8 vs 33.8 ms;
+// (2) IGEMM_EPI_EARLY (epilogue operands of 1x1 data gradients requested before the K loop): +-0; (3) IGEMM_FAT (8-wave workgroups
+// that split K, for grids of <= DMM_FAT_WGS workgroups): 300-workgroup launches get SLOWER (block-3 1x1: 25 -> 38 us), step 34.1 ms.
+// Ablation builds (tools/conv_time.py with IGEMM_DBG) say why: with every load, the prologue math and the MFMAs removed a 1x1
+// launch still takes 70-90 % of its time - the cost is the skeleton (LDS writes, barrier, fragment reads, staging, the per-channel
+// reductions and the stores of the epilogue), not latency that more bytes or waves in flight could hide.
 template <typename T, int BN, int EPI>
 static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
-  return launch_bn_ks<T, BN, EPI, ks_for(BN)>(a, mfma, st);
+  if constexpr (IGEMM_FAT && sizeof(T) == 2 && BN == 128 && EPI != EPI_LOGITS) {
+    static const int fat_wgs = getenv("DMM_FAT_WGS") ? atoi(getenv("DMM_FAT_WGS")) : 512;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += a.seg[s].nchunks;
+    const int wgs = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+    int kfl = 0;
+    for (int s = 0; s < a.nseg; ++s) kfl += seg_const_floats(a.seg[s]);
+    const int smem = IgemmSmem<T, BN, 2 * ks_for(BN)>::bytes(EPI) + kfl * 4 + nchunks * 16 + 16;
+    if (mfma && wgs <= fat_wgs && nchunks >= 8 && smem <= 160 * 1024) return launch_bn_ks<T, BN, EPI, 2 * ks_for(BN), 8>(a, mfma, st);
+  }
+  return launch_bn_ks<T, BN, EPI, ks_for(BN), 4>(a, mfma, st);
 }
 
 template <typename T, int EPI>
