@@ -11,6 +11,7 @@ Differences that are deliberate and documented:
 import ctypes as C
 import math
 import os
+import re
 from collections import OrderedDict
 
 import torch
@@ -377,9 +378,50 @@ class Dense_U_Net_lidar(nn.Module):
         }
 
 
-def _load_state_dict(model, config, model_url, progress):
-    raise RuntimeError("pretrained torchvision weights cannot be downloaded in this environment; load a checkpoint with "
-                       "model.load_state_dict(...) instead (state_dict keys match the reference)")
+_LEGACY_KEY = re.compile(r"^(.*denselayer\d+\.(?:norm|relu|conv))\.([12]\.(?:weight|bias|running_mean|running_var))$")
+
+
+def _find_checkpoint(source):
+    """`source` is a file path or a torchvision arch name looked up as $DMM_PRETRAINED_DIR/<arch>.pth (no download: the
+    reference fetches model_urls[arch] from the network, M:284; this build has none)."""
+    if isinstance(source, (str, os.PathLike)) and os.path.isfile(source):
+        return os.fspath(source)
+    root = os.environ.get("DMM_PRETRAINED_DIR")
+    if root:
+        for ext in (".pth", ".pt"):
+            cand = os.path.join(root, f"{source}{ext}")
+            if os.path.isfile(cand):
+                return cand
+    raise RuntimeError(f"no local torchvision checkpoint for {source!r}: pass pretrained=<path to densenetNNN .pth> or set "
+                       "DMM_PRETRAINED_DIR (pretrained weights cannot be downloaded in this environment)")
+
+
+def _load_state_dict(model, config, model_url, progress=True):
+    """Initialise the encoder(s) from a torchvision DenseNet checkpoint (reference M:269-309): old-style `norm.1` keys are
+    renamed, `features.conv0.weight` is skipped when the stem does not take 3 channels (early fusion or a non-RGB stream 1),
+    keys the model does not have (the classifier) are ignored, and for mid fusion the LiDAR stream starts as a copy of the
+    RGB stream except for its stem convolution."""
+    ckpt = torch.load(_find_checkpoint(model_url), map_location="cpu")
+    if isinstance(ckpt, dict) and "state_dict" in ckpt and not any(k.startswith("features.") for k in ckpt):
+        ckpt = ckpt["state_dict"]
+    renamed = {}
+    for key, value in ckpt.items():
+        m = _LEGACY_KEY.match(key)
+        renamed[m.group(1) + m.group(2) if m else key] = value
+    if model.fusion == "early" or model.stream_1_in_channels != 3:
+        renamed.pop("features.conv0.weight", None)
+    own = model.state_dict()
+    picked = {k: v for k, v in renamed.items() if k in own}
+    for k, v in picked.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise RuntimeError(f"checkpoint tensor {k} has shape {tuple(v.shape)}, the model expects {tuple(own[k].shape)}")
+    model.load_state_dict(picked, strict=False)
+    if model.fusion == "mid":
+        rgb = model.features.state_dict()
+        lidar_keys = set(model.stream_2_features.state_dict())
+        clone = {k: v for k, v in rgb.items() if k != "conv0.weight" and k in lidar_keys}
+        model.stream_2_features.load_state_dict(clone, strict=False)
+    return sorted(picked)
 
 
 def _dense_u_net_lidar(arch, growth_rate, block_config, num_init_features, pretrained, progress, config, **kw):
@@ -390,8 +432,8 @@ def _dense_u_net_lidar(arch, growth_rate, block_config, num_init_features, pretr
     config.model.block_config = block_config
     config.model.num_init_features = num_init_features
     model = Dense_U_Net_lidar(config, **kw)
-    if pretrained:
-        _load_state_dict(model, config, arch, progress)
+    if pretrained:  # True: $DMM_PRETRAINED_DIR/<arch>.pth; a string: that file
+        _load_state_dict(model, config, arch if pretrained is True else pretrained, progress)
     return model
 
 

@@ -83,6 +83,74 @@ def test_parameters_are_arena_views_and_survive_load(lib):
     assert abs(wt.std().item() / (1.0 / (3 * 1024 * 9)) ** 0.5 - 1) < 0.05
 
 
+def _fake_torchvision_checkpoint(depth, path):
+    """A checkpoint with torchvision's densenet layout: `features.*` keys in the pre-0.3 spelling (`norm.1.weight` ...),
+    a 3-channel stem and a classifier; values are random so that every tensor can be recognised after loading."""
+    import re
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    donor = Dense_U_Net_lidar(_cfg(depth, "no"))
+    g = torch.Generator().manual_seed(depth)
+    ckpt = {}
+    for k, v in donor.state_dict().items():
+        if not k.startswith("features."):
+            continue
+        old = re.sub(r"(denselayer\d+\.)(norm|conv)([12])\.", r"\1\2.\3.", k)
+        ckpt[old] = torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()
+    ckpt["classifier.weight"] = torch.randn(1000, 1024, generator=g)
+    ckpt["classifier.bias"] = torch.randn(1000, generator=g)
+    torch.save(ckpt, path)
+    return ckpt
+
+
+@pytest.mark.parametrize("variant", ["no", "early", "mid3"])
+def test_pretrained_torchvision_checkpoint_loading(lib, tmp_path, monkeypatch, variant):
+    """Reference M:269-309: legacy keys renamed, conv0 dropped unless the stem takes 3 channels, classifier ignored,
+    stream 2 cloned from stream 1 (except conv0) for mid fusion."""
+    import re
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import densenet121_u_lidar
+    path = tmp_path / "densenet121.pth"
+    ckpt = _fake_torchvision_checkpoint(121, path)
+    fresh = densenet121_u_lidar(config=_cfg(121, variant))
+    before = {k: v.clone() for k, v in fresh.state_dict().items()}
+    monkeypatch.setenv("DMM_PRETRAINED_DIR", str(tmp_path))
+    m = densenet121_u_lidar(pretrained=True, config=_cfg(121, variant))
+    m2 = densenet121_u_lidar(pretrained=str(path), config=_cfg(121, variant))
+    sd, sd2 = m.state_dict(), m2.state_dict()
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd if k.startswith("features.denseblock"))   # both spellings of `pretrained`
+    new = lambda k: re.sub(r"(denselayer\d+\.)(norm|conv)\.([12])\.", r"\1\2\3.", k)
+    own_features = [k for k in sd if k.startswith("features.")]
+    loaded = 0
+    for old_key, v in ckpt.items():
+        k = new(old_key)
+        if k.startswith("classifier"):
+            assert k not in sd
+            continue
+        if k not in sd:            # mid fusion: stream 1 ends at the fusion point... it does not: features.* is the full encoder
+            raise AssertionError(k)
+        if k == "features.conv0.weight" and variant == "early":
+            assert sd[k].shape[1] == 6 and not torch.equal(sd[k][:, :3], v)   # 6-channel stem keeps its own init
+            continue
+        assert torch.equal(sd[k], v), k
+        loaded += 1
+    assert loaded == len(own_features) - (1 if variant == "early" else 0)
+    # arena views survive: parameters still alias the flat arena
+    assert m.features.conv0.weight.data_ptr() == m.param_arena.data_ptr()
+    if variant == "mid3":
+        s2 = {k: v for k, v in sd.items() if k.startswith("stream_2_features.")}
+        assert s2
+        for k, v in s2.items():
+            twin = "features." + k[len("stream_2_features."):]
+            if k.endswith("conv0.weight"):
+                assert v.shape == before[k].shape            # LiDAR stem: own shape, own initialisation
+            elif not k.endswith("num_batches_tracked"):
+                assert torch.equal(v, sd[twin]), k
+    # untouched parts keep a fresh initialisation's statistics (decoder, head)
+    assert abs(sd["decoder.Transposed_Convolution_1.weight"].std().item() / before["decoder.Transposed_Convolution_1.weight"].std().item() - 1) < 0.05
+    monkeypatch.delenv("DMM_PRETRAINED_DIR")
+    with pytest.raises(RuntimeError):
+        densenet121_u_lidar(pretrained=True, config=_cfg(121, variant))
+
+
 def test_error_behaviour_matches_reference(lib):
     from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
     cfg = _cfg(121, "no")
