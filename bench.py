@@ -96,6 +96,13 @@ def collect_profile(model, plan, K, ops_out=None, enc=None):
     return classes
 
 
+def dominant_class(classes):
+    """The kernel class with the largest share of the serial pass.  "other" (unlabelled housekeeping launches: finalize kernels,
+    memsets) is not a kernel and cannot be bracketed by the class filter, so it never qualifies."""
+    named = {k: v for k, v in classes.items() if k != "other"} or classes
+    return max(named.items(), key=lambda kv: kv[1]["ms"])
+
+
 def measured_traffic(cls, workload):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py); bench.py cannot run the profiler around itself, so the figure comes from profiles/ and is only
@@ -132,11 +139,10 @@ def roofline_block(classes, dtype, workload=None, timed=None):
                           tflops=round(e["flops"] / t / 1e12, 2) if t else 0, gbs=round(e["bytes"] / t / 1e9, 1) if t else 0,
                           bound="mfma" if tf > tb else "hbm", frac=round(max(tf, tb) / t, 4) if t else 0))
     table.sort(key=lambda r: -r["ms_total"])
-    dom = max(classes.items(), key=lambda kv: kv[1]["ms"])
-    cls, e = dom
+    cls, e = dominant_class(classes)
     e_full = e
     alone_ms = e["ms"] / max(e["launches"], 1)
-    if timed and cls in timed and timed[cls]["launches"]:
+    if timed and cls in timed and timed[cls]["launches"] and timed[cls]["ms"] > 0:
         e = timed[cls]  # the same launches, bracketed inside the timed region (other streams running beside them)
     t = e["ms"] / 1e3
     tf, tb = e["flops"] / peak_f, e["bytes"] / peak_b
@@ -211,13 +217,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or bool(os.environ.get("DMM_FORCE_DIST"))  # the second form exercises the N>1 code path on one GPU
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal of the N > 1 code path on a ONE-GPU box (tests/test_dp_gpu.py): DMM_DIST_BACKEND=gloo DMM_DIST_SAME_DEVICE=1 puts
+    # every rank on cuda:0 and exchanges through gloo (RCCL refuses two ranks on one device).  Never the measured configuration.
+    backend = os.environ.get("DMM_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DMM_DIST_SAME_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dmmfods_amd import _lib
     from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
@@ -268,8 +281,7 @@ def main():
         enc = {}
         full_classes = collect_profile(model, plan, 1, ops_list, enc)
         if full_classes and rank == 0:
-            dom = max(full_classes.items(), key=lambda kv: kv[1]["ms"])[0]
-            dom_prefix = (dom + "/").encode()
+            dom_prefix = (dominant_class(full_classes)[0] + "/").encode()
         if distributed:
             obj = [dom_prefix]
             dist.broadcast_object_list(obj, src=0)

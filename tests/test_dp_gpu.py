@@ -116,3 +116,75 @@ def test_bucketed_allreduce_over_rccl_keeps_single_rank_gradients():
         _lib.check(_lib.lib().dmm_set_option(b"grad_bucket_mb", 25))
         if created:
             dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _torchrun(args, env_extra, timeout=600):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=os.path.dirname(os.path.dirname(__file__)))
+
+
+def test_two_ranks_exchange_equals_sum_of_replicas(tmp_path):
+    """Two PROCESSES (both on this GPU, gloo transport) run one data-parallel step: different initial weights are overwritten by
+    the broadcast, each rank takes its half of the batch, buckets are exchanged behind their readiness events.  Afterwards
+    both ranks must hold the same gradients = the sum of the two replicas' gradients computed here in one process, and the
+    same updated weights."""
+    from oracle import restatement as R
+    from dmmfods_amd.optim import FusedAdam
+    out = str(tmp_path / "dp")
+    r = _torchrun([os.path.join(os.path.dirname(__file__), "dp_rehearsal_worker.py"), out], {})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = [torch.load(f"{out}.rank{i}") for i in range(2)]
+    arch = R.Arch(**G3_ARCH, concat_before_block_num=3, stream_2_in_channels=3)
+    rgb, lidar, tgt = R.make_inputs(arch, 4, 64, 96, seed=21)
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=9))
+    model = model.to(DEV).train()
+    total = torch.zeros_like(model.grad_arena)
+    for half in (slice(0, 2), slice(2, 4)):
+        with torch.no_grad():
+            model(rgb[half].to(DEV), lidar[half].to(DEV))
+        model.loss_backward(tgt[half].to(DEV))
+        total += model.grad_arena
+    torch.cuda.synchronize()
+    want = total.cpu()
+    scale = want.abs().max()
+    for i in range(2):
+        assert [tuple(x) for x in got[i]["ranges"]] == [tuple(x) for x in model.grad_buckets()]
+        err = (got[i]["grads"] - want).abs().max() / scale
+        assert err < 1e-5, (i, float(err))          # fp32 atomics order is the only difference
+    assert torch.equal(got[0]["grads"], got[1]["grads"])      # an all-reduce leaves identical bits on every rank
+    assert torch.equal(got[0]["params"], got[1]["params"])    # ... and so does Adam behind it
+    # the update really happened, from rank 0's initial state
+    model.grad_arena.copy_(want.to(DEV))
+    FusedAdam(model, lr=1e-3).step()
+    torch.cuda.synchronize()
+    assert (got[0]["params"] - model.param_arena.cpu()).abs().max() < 1e-6
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py under torch.distributed.run with two ranks (gloo, one GPU): the N > 1 branch end to end - barrier-bracketed
+    timing, MAX over ranks, one JSON line from rank 0 with n_gpus = 2 and the whole-job image rate."""
+    import json
+    root = os.path.dirname(os.path.dirname(__file__))
+    r = _torchrun([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c1", "--no-cpu-baseline"],
+                  {"DMM_DIST_BACKEND": "gloo", "DMM_DIST_SAME_DEVICE": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"] and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    assert d["scaling"] == "weak" and d["roofline"] and d["roofline"]["frac"] > 0
