@@ -39,6 +39,7 @@ int dmm_set_option(const char* name, int value) {
   if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "conv3") { dmm::conv3_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "wg3") { dmm::wg3_set_enabled(value != 0); return DMM_OK; }
+  if (std::string(name) == "wgp") { dmm::wgp_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "grad_bucket_mb") {  // applies to plans created afterwards; 0 = one bucket
     if (value < 0) return fail(DMM_ERR_INVALID, "grad_bucket_mb must be >= 0");
     g_bucket_mb = value;
@@ -153,7 +154,10 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       int lo = 0, hi = 0;
       hipDeviceGetStreamPriorityRange(&lo, &hi);
       hipStream_t s2;
-      if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
+      // DMM_SIDE_PRIO = hi | mid: experiment knob (default: lowest priority, the data-gradient chain is the longer dependency chain)
+      const char* sp = getenv("DMM_SIDE_PRIO");
+      const int prio = sp && sp[0] == 'h' ? hi : (sp && sp[0] == 'm' ? (lo + hi) / 2 : lo);
+      if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio) != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
       hipEvent_t je;
       if (hipEventCreateWithFlags(&je, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
       p->side_streams.push_back((void*)s2);

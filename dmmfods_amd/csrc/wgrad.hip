@@ -427,6 +427,7 @@ extern template hipError_t launch_wt<float>(const WgradArgs&, bool, hipStream_t)
 extern template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
 
 hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st);  // wg3.hip
+hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st);  // wgp.hip
 
 // Fills rows_per_split / kgroups (if zero) and launches.
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
@@ -434,6 +435,17 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (mfma) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
     const hipError_t e = launch_wg3(a, dtype, st);
     if (e != hipErrorNotSupported) return e;
+  }
+  if (mfma) {  // parity-phase convolutions (ConvTranspose stages, the head's 3x3 over the upsampled map): all taps of a phase per tile
+    const hipError_t e = launch_wgp(a, dtype, st);
+    if (e == hipSuccess) {
+      if (a.nseg == 1) return e;
+      // the 8-channel raw-input segment of the head convolution stays with the generic kernel: its chunks follow segment 0's
+      a.dpack += (size_t)a.seg[0].nchunks * a.Npad * 32;
+      a.seg[0] = a.seg[1];
+      a.nseg = 1;
+      a.rows_per_split = 0;
+    } else if (e != hipErrorNotSupported) return e;
   }
   const int BK = dtype == DT_F32 ? 16 : 32;
   const int bmw = dtype == DT_F32 ? 32 : 64;

@@ -38,3 +38,25 @@ def test_ragged_and_tail_shapes(lab, dtype):
               ("convT 1x1 map", 2, 1, 1, 8, 8, 3, 3, 2, 1, 1, 0, 1),
               ("pool2 2x2 map", 1, 2, 2, 16, 8, 1, 1, 1, 0, 0, 2, 1)]:
         assert lab.conv_case(c[0], dtype, 1, *c[1:])
+
+
+@pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
+def test_parity_phase_weight_gradients_on_lds_tiles(lab, dtype):
+    """wgp.hip (all taps of a ConvTranspose / upsampled-3x3 phase per LDS tile): shapes that take it - input channels a multiple of
+    128, output a multiple of 64 - with ragged 8x16 tiles, several channel tiles and both accumulator shapes, against the torch
+    reference AND against the generic kernel on identical operands."""
+    import ctypes as C
+    from dmmfods_amd import _lib
+    L = _lib.lib()
+    cases = [("convT 128->64 ragged", 2, 12, 20, 128, 64, 3, 3, 2, 1, 1, 0, 1),
+             ("convT 256->128", 1, 9, 17, 256, 128, 3, 3, 2, 1, 1, 0, 1),
+             ("convT 128->192", 1, 8, 16, 128, 192, 3, 3, 2, 1, 1, 0, 1),
+             ("up2 3x3 128->64", 2, 10, 18, 128, 64, 3, 3, 1, 1, 0, 1, 1)]
+    for c in cases:
+        assert lab.conv_case(c[0], dtype, 1, *c[1:])
+    try:
+        _lib.check(L.dmm_set_option(b"wgp", 0))
+        for c in cases:
+            assert lab.conv_case(c[0] + " (generic)", dtype, 1, *c[1:])
+    finally:
+        _lib.check(L.dmm_set_option(b"wgp", 1))

@@ -413,3 +413,48 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
     worst = max(((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm()).item() for k in grads[1])
     print(f"   wg3 vs generic on identical operands: worst conv2.weight gradient rel L2 {worst:.3e}")
     assert len(grads[1]) >= 9 and worst < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
+    """wgp.hip (weight gradients of the ConvTranspose stages and of the head's 3x3 over the upsampled map, all taps of a parity
+    phase per LDS tile) against the generic kernel inside DenseNet-121 (decoder 1024 -> 512 -> 256 -> 128 channels), maps that
+    are not multiples of the 8 x 16 tile.  Nothing upstream of a weight gradient changes with the switch, so both kernels see
+    bit-identical operands and only the fp32 summation order differs."""
+    import ctypes as C
+    from oracle import restatement as R
+    from dmmfods_amd import _lib
+    arch = _arch(R, R.DENSENETS[121], "early")
+    model = _model(arch, dtype=dtype)
+    model.load_state_dict(R.make_state(arch, seed=23))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = R.make_inputs(arch, 2, 96, 160, seed=6)
+    rgb, lidar, tgt = rgb.to(DEV), lidar.to(DEV), tgt.to(DEV)
+    L = _lib.lib()
+    grads = {}
+    try:
+        for on in (1, 0):
+            _lib.check(L.dmm_set_option(b"wgp", on))
+            with torch.no_grad():
+                model(rgb, lidar)
+            model.loss_backward(tgt)
+            torch.cuda.synchronize()
+            grads[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters()
+                         if "Transposed_Convolution_" in k and k.endswith(".weight") and "Sequence" not in k or k.endswith("refine0.weight")}
+    finally:
+        _lib.check(L.dmm_set_option(b"wgp", 1))
+    # the plan labels its launches by the kernel that runs them: the phases with 2 or 4 taps must be on wgp
+    plan = model._last[0]
+    n = L.dmm_plan_profile_num_ops(plan.handle, 1)
+    labels = []
+    for i in range(n):
+        label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+        L.dmm_plan_profile_op(plan.handle, 1, i, C.byref(label), C.byref(fl), C.byref(by))
+        labels.append((label.value or b"").decode())
+    on_wgp = [x for x in labels if x.startswith("wgp.")]
+    assert len(on_wgp) >= 3 * 4, on_wgp                       # 3 multi-tap phases x 4 ConvTranspose stages (+ the head's 4 if eligible)
+    assert len(grads[1]) == 5
+    worst = max(((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm()).item() for k in grads[1])
+    print(f"wgp vs generic on identical operands ({dtype}): worst rel L2 {worst:.3e}; launches on wgp: {len(on_wgp)}")
+    assert all(torch.isfinite(v).all() for v in grads[1].values()) and worst < 2e-4
