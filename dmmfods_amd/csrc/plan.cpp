@@ -259,6 +259,9 @@ struct Buf {
   bool ginit = false;
   bool matz = false;          // single-consumer tensor whose gradient is re-gathered often: materialise q + r*x once
   bool materialized = false;  // (set during backward emission) gradient already holds the effective gradient
+  int front = 0;              // leading channels written by a ConvTranspose (the decoder concat): one BatchNorm consumer, re-gathered by that
+                              // ConvTranspose's data gradient (72x per element) and weight gradients -> their correction is applied once
+  int mat_front = 0;          // (set during backward emission) channels [0, mat_front) already hold the effective gradient
 };
 
 struct BnRange { int buf, ch0, c0, n; double count, count_unb; bool want_qr; };
@@ -423,6 +426,7 @@ struct Builder {
 
   // -------------------------------------------------------------------------------- op emission
   bool leaf_scope = false;  // ops emitted now feed only parameter gradients (stem / raw-input branches)
+  const bool front_matz = getenv("DMM_NO_FRONT_MATZ") == nullptr;  // A/B knob
   Op& push(int kind) {
     ops->emplace_back();
     ops->back().kind = kind;
@@ -551,7 +555,7 @@ struct Builder {
     s.C = C; s.Cpad = C;
     s.mode = G_PLAIN;
     s.istride = istride;
-    if (b.q && !b.materialized) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; s.ql = b.ql + ch0; s.rl = b.rl + ch0; }
+    if (b.q && !b.materialized && ch0 + C > b.mat_front) { s.src2 = xat(buf, ch0); s.ld2 = b.ld; s.q = b.q + ch0; s.r = b.r + ch0; s.ql = b.ql + ch0; s.rl = b.rl + ch0; }
     fill_seg_taps(s, taps, BK);
   }
 
@@ -590,6 +594,18 @@ struct Builder {
       tag(o, "applycorr", "grad", 0, 3.0 * a.npix * a.C * esz);
       sb.materialized = true;
     }
+    for (auto& rg : b.ranges) {  // the ConvTranspose-written front of a decoder concat buffer: final after this BatchNorm
+      Buf& sb = bufs[rg.buf];
+      if (!(rg.want_qr && sb.q && sb.front > 0 && rg.ch0 == 0 && rg.n >= sb.front) || sb.materialized || sb.mat_front || !front_matz) continue;
+      Op& o = push(OP_APPLYCORR);
+      ApplyCorrArgs& a = o.ac;
+      a.g = gat(rg.buf, 0); a.y = xat(rg.buf, 0);
+      a.q = sb.q; a.r = sb.r; a.ql = sb.ql; a.rl = sb.rl;
+      a.npix = (size_t)sb.B * sb.H * sb.W;
+      a.C = sb.front; a.ldg = sb.ld; a.ldy = sb.ld;
+      tag(o, "applycorr", "grad", 0, 3.0 * a.npix * a.C * esz);
+      sb.mat_front = sb.front;
+    }
   }
 
   void emit_conv_bwd(ConvRec& c) {
@@ -613,7 +629,7 @@ struct Builder {
       a.dpack = (float*)pd.dpack;
       char cb[32];
       tag(o, ncls((d.use_mfma && wg3_handles(a, dtype)) ? "wg3" : "wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
-          src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
+          src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
     } else
     for (auto& ph : c.phases) {
       Op& o = push(OP_WGRAD);
@@ -632,7 +648,7 @@ struct Builder {
         const double np = (double)c.phases.size();
         // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
         tag(o, ncls((d.use_mfma && wgp_handles(a, dtype)) ? "wgp" : "wgrad", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
-            (src_bytes(c) + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
+            (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
     conv_grad_done(c);
@@ -682,7 +698,7 @@ struct Builder {
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
         const bool c3 = d.use_mfma && conv3_handles(a, dtype, EPI_BNBWD);
         tag(o, ncls(c3 ? "conv3.bnbwd" : "igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
-            ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
+            ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
       if (!raw) sb.ginit = true;
     }
@@ -915,6 +931,7 @@ struct Builder {
       if (j < g.nb - 1) ob = X[g.nb - 2 - j];
       else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true, /*matz=*/true);
       if (bufs[ob].H != 2 * I.H) throw std::runtime_error("decoder size mismatch");
+      if (j < g.nb - 1 && nf % 8 == 0) bufs[ob].front = nf;
       {
         ConvRec& c = new_conv("decoder.Transposed_Convolution_" + std::to_string(j + 1) + ".weight", true, nf, nf, 3, 3, 1);
         set_seg(c, 0, Rb, 0, nf, 0, G_PLAIN, 1, n1, 0, DG_CONVT);
@@ -1147,7 +1164,7 @@ struct Builder {
       P.bce_only = o;
       P.bce_only.bce.dlogits = nullptr;
     }
-    for (auto& b : bufs) { b.ginit = false; b.materialized = false; }
+    for (auto& b : bufs) { b.ginit = false; b.materialized = false; b.mat_front = 0; }
     for (int i = (int)recs.size() - 1; i >= 0; --i) {
       if (recs[i].type == 0) emit_conv_bwd(convs[recs[i].idx]); else emit_pool_bwd(pools[recs[i].idx]);
     }

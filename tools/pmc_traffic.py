@@ -25,6 +25,8 @@ def classify(name):
         return f"conv3.{EPI.get(m.group(2), m.group(2))}.n{32 * int(m.group(1))}"
     if "wg3_kernel" in name:
         return "wg3.n128"
+    if "wgp_kernel" in name:
+        return "wgp"
     m = re.search(r"halo_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"igemm.{EPI.get(m.group(2), m.group(2))}.n{m.group(1)}"
