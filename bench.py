@@ -213,6 +213,12 @@ def main():
     ap.add_argument("--ops", type=int, default=0, help="print the N most expensive launches (per step) to stderr")
     args = ap.parse_args()
 
+    # Native libraries write to file descriptor 1 (RCCL prints its version banner there when the first communicator comes up).
+    # The contract is ONE JSON line on stdout, so everything else that lands on fd 1 goes to stderr and the line is written to
+    # the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -345,7 +351,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

@@ -182,9 +182,28 @@ def test_bench_two_ranks_rehearsal():
     r = _torchrun([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c1", "--no-cpu-baseline"],
                   {"DMM_DIST_BACKEND": "gloo", "DMM_DIST_SAME_DEVICE": "1"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # ONE line on stdout, whatever native libraries print
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"] and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
     assert d["scaling"] == "weak" and d["roofline"] and d["roofline"]["frac"] > 0
+
+
+def test_bench_stdout_is_one_json_line_with_rccl():
+    """The RCCL communicator prints a version banner to file descriptor 1; bench.py must still put exactly one JSON line on
+    stdout (forced single-rank distributed run: the collectives are real)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(__file__))
+    env = dict(os.environ, DMM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
