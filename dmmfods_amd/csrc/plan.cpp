@@ -628,7 +628,7 @@ struct Builder {
       a.N = c.seg[0].C; a.Npad = pd.Npad;
       a.dpack = (float*)pd.dpack;
       char cb[32];
-      tag(o, ncls((d.use_mfma && wg3_handles(a, dtype)) ? "wg3" : "wgradT", pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
+      tag(o, ncls((d.use_mfma && wg3_handles(a, dtype)) ? "wg3" : ((d.use_mfma && wg5_handles(a, dtype)) ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
           src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
     } else
     for (auto& ph : c.phases) {

@@ -145,9 +145,11 @@ void thin_set_enabled(bool on);  // thin.hip
 void conv3_set_enabled(bool on);  // conv3.hip
 void wg3_set_enabled(bool on);    // wg3.hip
 void wgp_set_enabled(bool on);    // wgp.hip
+void wg5_set_enabled(bool on);    // wg5.hip
 bool conv3_handles(const ConvArgs& a, int dtype, int epi);
 bool wg3_handles(const WgradArgs& a, int dtype);
 bool wgp_handles(const WgradArgs& a, int dtype);
+bool wg5_handles(const WgradArgs& a, int dtype);
 hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st);
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st);

@@ -1,0 +1,245 @@
+// Weight gradient of the heat-map head's last convolution `refine1` (5x5, 64 -> 3 channels at full resolution; reference
+// M:128-131) on LDS tiles, gfx950, 16-bit storage types.
+//
+//   dW[n][c][tap] = sum over pixels p of  A[p][c] * dY[p + t_tap][n]          (transposed form of wgrad.hip: taps on the dY side)
+//     A  = relu(bn(x))   64 channels, normalised ONCE per pixel
+//     dY = dL/dlogits    3 channels stored as one 16-byte slot of 8
+// The result has 25 x 8 = 200 (tap, n) columns per input channel: seven 32-column chunks of the packed gradient, four taps each.
+// The generic kernel runs this as a GEMM with K = 200 gathered from dY tap by tap and re-reads (and re-normalises) A for every
+// chunk group: 1.2 TB/s on a layer whose whole traffic is one pass over A (1.26 GB at C2).  Here a PERSISTENT workgroup walks
+// 8 x 16 pixel tiles: A tile (128 px x 64 ch) and the 12 x 20 pixel dY halo go to LDS once, the (tap, n) columns of a chunk are
+// simply per-lane addresses into the halo image (a lane's four consecutive columns belong to one tap), both operands come from
+// ds_read_b64_tr_b16, and the 7 x 64 x 32 result lives in the accumulators of the four waves until the end (one round of atomics).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "gather.h"
+
+namespace dmm {
+
+constexpr int W5_TH = 8, W5_TW = 16, W5_HH = 12, W5_HW = 20;  // tile, halo (taps span -2..2)
+constexpr int W5_CA = 64;
+constexpr int W5_NCH = 7;                                     // 25 taps x 8 columns = 200 -> seven 32-column chunks
+constexpr int W5_A_BYTES = BM * W5_CA * 2;                    // 16 KB, 128-byte rows, 64-byte granule XOR-ed with (row >> 1) & 1
+constexpr int W5_Y_BYTES = W5_HH * W5_HW * 16 + 64;           // halo image + a zero line for the 3 columns groups past tap 24
+constexpr int W5_LDS = W5_A_BYTES + W5_Y_BYTES;
+
+struct Wg5Args {
+  WgradArgs w;
+  int tiles_y, tiles_x, ntiles, tiles_per_wg;
+};
+
+typedef unsigned w5_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ w5_u32x2 w5_tr16(const unsigned char* p) {
+  typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(p));
+  return __builtin_bit_cast(w5_u32x2, r);
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec w5_frag(const w5_u32x2& lo, const w5_u32x2& hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(typename TT<T>::vec, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  typedef typename TT<T>::vec V;
+  constexpr int SLOT = 8;
+  constexpr int NA = BM * (W5_CA / SLOT) / NTHREADS;  // 4 A slots per thread
+  const WgradArgs& a = g.w;
+  const Seg& sy = a.seg[0];  // dY, 25 taps
+  const Seg& sa = a.dy;      // A, pixel aligned
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;
+  unsigned char* Ys = smem + W5_A_BYTES;
+  constexpr int ZERO = W5_HH * W5_HW * 16;  // offset of the zero line in the dY image
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t_beg = blockIdx.x * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
+  if (t_beg >= t_end) return;
+
+  // ---- fixed channel positions: prologue constants once ----
+  const int ca = tid & 7, pa0 = tid >> 3;  // A: slot column, pixels pa0 + 32 i
+  SlotK<SLOT> ka;
+  ka.k0 = load_fv<SLOT>(sa.scale + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.shift + ca * SLOT); ka.k2 = 0.f; ka.k3 = 0.f;
+  const T* asrc = (const T*)sa.src + ca * SLOT;
+  const T* ysrc = (const T*)sy.src;
+  const int hy_ = tid / W5_HW, hx_ = tid - hy_ * W5_HW;  // dY: halo pixel `tid` (threads 0..239)
+  int alds[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int p = pa0 + 32 * i;
+    alds[i] = p * 128 + ((ca * 16) ^ (((p >> 1) & 1) << 6));
+  }
+  if (tid < 4) *(V*)(Ys + ZERO + tid * 16) = V{};  // the zero line (never rewritten)
+
+  // Two register sets: the loads of tile t + 2 are issued while tile t is contracted (a tile's contraction is short next to a
+  // memory latency).  Every load is issued unconditionally (clamped tile / pixel), so the number of loads behind a given one is a
+  // compile-time constant and the compiler's counted s_waitcnt in store() leaves the other set in flight.
+  struct Regs {
+    V ra[NA], ry;
+    unsigned oka;
+    bool oky;
+  };
+  Regs R0, R1;
+  const int tiles_img = g.tiles_y * g.tiles_x;
+  auto issue = [&](Regs& R, int tile_) {
+    const int tile = min(tile_, t_end - 1);  // past the end: the last tile again (never stored)
+    const int b = tile / tiles_img, tr = tile - b * tiles_img;
+    const int y0 = (tr / g.tiles_x) * W5_TH, x0 = (tr % g.tiles_x) * W5_TW;
+    R.oka = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {  // branch-free: clamped address, zeroed at the write if outside
+      const int p = pa0 + 32 * i;
+      const int y = y0 + (p >> 4), x = x0 + (p & 15);
+      if (y < a.Ho && x < a.Wo) R.oka |= 1u << i;
+      const size_t pix = (size_t)(b * sa.Hs + min(y, sa.Hs - 1)) * sa.Ws + min(x, sa.Ws - 1);
+      R.ra[i] = *(const V*)(asrc + pix * sa.ld);
+    }
+    const int y = y0 - 2 + hy_, x = x0 - 2 + hx_;
+    R.oky = tid < W5_HH * W5_HW && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws;
+    const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
+    R.ry = *(const V*)(ysrc + pix * sy.ld);
+  };
+  auto store = [&](const Regs& R) {
+    V z;
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const V v = bn_relu_slot(R.ra[i], ka);
+      *(V*)(As + alds[i]) = ((R.oka >> i) & 1) ? v : z;
+    }
+    if (tid < W5_HH * W5_HW) *(V*)(Ys + tid * 16) = R.oky ? R.ry : z;
+  };
+
+  // wave w: input channels 32 (w & 1) .., chunks (w >> 1), (w >> 1) + 2, ...  (4 chunks for waves 0-1, 3 for waves 2-3)
+  constexpr int NQ = 4;
+  const int cw = wave & 1, q0 = wave >> 1;
+  f32x16 acc[NQ];
+#pragma unroll
+  for (int m = 0; m < NQ; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+
+  // transposed-read lane geometry (see wgrad.hip): group tg = lane >> 4 covers columns 16 (tg & 1) .., rows 8 (tg >> 1) + tq (+4)
+  const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+  const int arow = 8 * (tg >> 1) + tq;
+  const int acol = ((32 * cw + 16 * (tg & 1) + 4 * tp) * 2) ^ (((arow >> 1) & 1) << 6);
+  // a lane's four consecutive (tap, n) columns 16 (tg & 1) + 4 tp .. belong to tap 4 q + 2 (tg & 1) + (tp >> 1), n = 4 (tp & 1) ..
+  int boff[NQ], bstep[NQ], bsec[NQ];
+#pragma unroll
+  for (int m = 0; m < NQ; ++m) {
+    const int q = q0 + 2 * m;
+    const int tap = 4 * q + 2 * (tg & 1) + (tp >> 1);
+    const bool live = q < W5_NCH && tap < sy.ntaps;
+    const int tw = sy.taps[live ? tap : 0];
+    const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
+    boff[m] = live ? ((2 + dy) * W5_HW + arow + 2 + dx) * 16 + (tp & 1) * 8 : ZERO + (tp & 1) * 8;
+    bstep[m] = live ? W5_HW * 16 : 0;  // one tile row further in the halo image
+    bsec[m] = live ? 4 * 16 : 0;       // the fragment's second half: 4 pixels further
+  }
+
+  auto contract = [&]() {
+#pragma unroll 2
+    for (int ms = 0; ms < W5_TH; ++ms) {  // one tile row = 16 pixels of the contraction per step
+      const unsigned char* ap = As + (16 * ms + arow) * 128 + acol;
+      const V af = w5_frag<T>(w5_tr16(ap), w5_tr16(ap + 4 * 128));
+#pragma unroll
+      for (int m = 0; m < NQ; ++m) {
+        if (q0 + 2 * m < W5_NCH) {  // (wave-uniform)
+          const unsigned char* yp = Ys + boff[m] + ms * bstep[m];
+          const V bf = w5_frag<T>(w5_tr16(yp), w5_tr16(yp + bsec[m]));
+          acc[m] = mma16(af, bf, acc[m]);
+        }
+      }
+    }
+  };
+  issue(R0, t_beg);
+  issue(R1, t_beg + 1);
+  for (int tile = t_beg; tile < t_end; tile += 2) {
+    store(R0);        // waits for this tile's loads (R1's stay in flight)
+    __syncthreads();  // images complete
+    issue(R0, tile + 2);
+    contract();
+    __syncthreads();  // all waves done with the images
+    if (tile + 1 >= t_end) break;
+    store(R1);
+    __syncthreads();
+    issue(R1, tile + 3);
+    contract();
+    __syncthreads();
+  }
+
+  // ---- add the partial result to the packed gradient: dP[chunk][c][k % 32] ----
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NQ; ++m) {
+    const int q = q0 + 2 * m;
+    if (q >= W5_NCH) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * h;
+      atomic_add_f32(a.dpack + ((size_t)q * a.Npad + c) * 32 + r, acc[m][i]);
+    }
+  }
+}
+
+static bool g_wg5 = getenv("DMM_NO_WG5") == nullptr;
+void wg5_set_enabled(bool on) { g_wg5 = on; }
+
+static thread_local bool g_wg5_dry = false;
+
+template <typename T>
+static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
+  hipLaunchKernelGGL(wg5_kernel<T>, dim3(nwg), dim3(NTHREADS), W5_LDS, st, g);
+  return hipGetLastError();
+}
+
+// Returns hipErrorNotSupported unless this is the transposed-form weight gradient of a 5x5 convolution from 64 channels to one
+// 8-channel slot in a 16-bit storage type.
+hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
+  if (!g_wg5 || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
+  const Seg& q = a.seg[0];
+  const Seg& p = a.dy;
+  if (q.mode != G_PLAIN || q.istride != 1 || q.ntaps != 25 || q.C != 8 || q.Cpad != 8 || q.Hs != a.Ho || q.Ws != a.Wo || q.scale != nullptr || q.q != nullptr)
+    return hipErrorNotSupported;
+  if (q.nchunks != W5_NCH) return hipErrorNotSupported;
+  if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo || p.scale == nullptr)
+    return hipErrorNotSupported;
+  if (a.N != W5_CA || a.Npad != W5_CA) return hipErrorNotSupported;
+  bool seen[25];
+  for (int t = 0; t < 25; ++t) seen[t] = false;
+  for (int t = 0; t < 25; ++t) {
+    const int dy = (int)(signed char)(q.taps[t] & 0xff), dx = (int)(signed char)((q.taps[t] >> 8) & 0xff);
+    if (dy < -2 || dy > 2 || dx < -2 || dx > 2 || seen[(dy + 2) * 5 + dx + 2]) return hipErrorNotSupported;
+    seen[(dy + 2) * 5 + dx + 2] = true;
+  }
+  if (g_wg5_dry) return hipSuccess;
+  Wg5Args g;
+  g.w = a;
+  g.tiles_y = (a.Ho + W5_TH - 1) / W5_TH;
+  g.tiles_x = (a.Wo + W5_TW - 1) / W5_TW;
+  g.ntiles = a.B * g.tiles_y * g.tiles_x;
+  static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
+                              return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  static const int per_cu = getenv("DMM_WG5_PER_CU") ? atoi(getenv("DMM_WG5_PER_CU")) : 2;
+  // every workgroup ends with 57 KB of atomics; a tile costs ~1 us: two workgroups per CU unless the picture is small
+  int nwg = std::max(1, std::min(per_cu * cus, g.ntiles / 8));
+  g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;
+  nwg = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
+  return dtype == DT_F16 ? launch_wg5_t<f16>(g, nwg, st) : launch_wg5_t<bf16>(g, nwg, st);
+}
+
+bool wg5_handles(const WgradArgs& a, int dtype) {
+  g_wg5_dry = true;
+  const hipError_t e = launch_wg5(a, dtype, nullptr);
+  g_wg5_dry = false;
+  return e == hipSuccess;
+}
+
+}  // namespace dmm

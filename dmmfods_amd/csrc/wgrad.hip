@@ -428,12 +428,17 @@ extern template hipError_t launch_wt<bf16>(const WgradArgs&, bool, hipStream_t);
 
 hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st);  // wg3.hip
 hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st);  // wgp.hip
+hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st);  // wg5.hip
 
 // Fills rows_per_split / kgroups (if zero) and launches.
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (mfma) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
     const hipError_t e = launch_wg3(a, dtype, st);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (mfma) {  // the head's 5x5 convolution onto 3 classes: persistent tiles, the 25 x 8 (tap, class) columns as per-lane addresses
+    const hipError_t e = launch_wg5(a, dtype, st);
     if (e != hipErrorNotSupported) return e;
   }
   if (mfma) {  // parity-phase convolutions (ConvTranspose stages, the head's 3x3 over the upsampled map): all taps of a phase per tile
