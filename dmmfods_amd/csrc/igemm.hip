@@ -667,6 +667,7 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // halo.hip
 hipError_t launch_thin_logits(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // thin.hip
 hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st);        // conv3.hip
+hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st);          // cvp.hip
 
 // One translation unit per storage type (IGEMM_PART = 0 fp32, 1 f16, 2 bf16; see the Makefile): the ~50 kernel instantiations
 // of a type compile in parallel with the other types'.
@@ -698,6 +699,10 @@ hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStr
   }
   if (mfma) {  // 3x3 convolutions of the dense layers (16-bit storage): LDS halo tile, prologue once per element
     const hipError_t e = launch_conv3(a, dtype, epi, st);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (mfma) {  // forward of the ConvTranspose parity phases: halo tile per 128-channel group, a tap is a fragment address
+    const hipError_t e = launch_cvp(a, dtype, epi, st);
     if (e != hipErrorNotSupported) return e;
   }
   static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;

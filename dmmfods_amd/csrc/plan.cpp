@@ -537,7 +537,8 @@ struct Builder {
         char cb[32];
         const double np = (double)c.phases.size();
         const bool c3 = d.use_mfma && conv3_handles(a, dtype, c.epi);
-        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : (c3 ? "conv3.store" : "igemm.store"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        const bool cp = d.use_mfma && !c3 && cvp_handles(a, dtype, c.epi);
+        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : (c3 ? "conv3.store" : (cp ? "cvp.store" : "igemm.store")), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + out_bytes(c)) / np + w_bytes(c) / np);
       }
       if (c.epi == EPI_LOGITS) {

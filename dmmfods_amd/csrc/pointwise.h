@@ -146,6 +146,8 @@ void conv3_set_enabled(bool on);  // conv3.hip
 void wg3_set_enabled(bool on);    // wg3.hip
 void wgp_set_enabled(bool on);    // wgp.hip
 void wg5_set_enabled(bool on);    // wg5.hip
+void cvp_set_enabled(bool on);    // cvp.hip
+bool cvp_handles(const ConvArgs& a, int dtype, int epi);
 bool conv3_handles(const ConvArgs& a, int dtype, int epi);
 bool wg3_handles(const WgradArgs& a, int dtype);
 bool wgp_handles(const WgradArgs& a, int dtype);

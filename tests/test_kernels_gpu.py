@@ -51,12 +51,16 @@ def test_parity_phase_weight_gradients_on_lds_tiles(lab, dtype):
     cases = [("convT 128->64 ragged", 2, 12, 20, 128, 64, 3, 3, 2, 1, 1, 0, 1),
              ("convT 256->128", 1, 9, 17, 256, 128, 3, 3, 2, 1, 1, 0, 1),
              ("convT 128->192", 1, 8, 16, 128, 192, 3, 3, 2, 1, 1, 0, 1),
+             ("convT 384->256 ragged", 2, 11, 19, 384, 256, 3, 3, 2, 1, 1, 0, 1),   # forward on cvp.hip: 3 channel groups, 2 column tiles
+             ("convT 128->128 1 tile", 1, 3, 5, 128, 128, 3, 3, 2, 1, 1, 0, 1),
              ("up2 3x3 128->64", 2, 10, 18, 128, 64, 3, 3, 1, 1, 0, 1, 1)]
     for c in cases:
         assert lab.conv_case(c[0], dtype, 1, *c[1:])
     try:
         _lib.check(L.dmm_set_option(b"wgp", 0))
+        _lib.check(L.dmm_set_option(b"cvp", 0))
         for c in cases:
             assert lab.conv_case(c[0] + " (generic)", dtype, 1, *c[1:])
     finally:
         _lib.check(L.dmm_set_option(b"wgp", 1))
+        _lib.check(L.dmm_set_option(b"cvp", 1))

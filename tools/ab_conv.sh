@@ -1,6 +1,7 @@
 #!/bin/bash
-out=gpurun_out/$1; shift; mkdir -p $out
+# tools/ab_conv.sh <out-tag> <VAR> <value...>: tools/conv_time.py under each value of an environment knob ("-" = unset)
+out=gpurun_out/$1; var=$2; shift 2; mkdir -p $out
 for v in "$@"; do
-  if [ "$v" = main ]; then unset DMM_LIB_PATH; else export DMM_LIB_PATH=$PWD/build_var/lib_$v.so; fi
-  echo "== $v"; DMM_FAT_WGS=0 timeout -k 10 120 python3 tools/conv_time.py 20 2>&1 | grep -v amdgpu.ids
+  if [ "$v" = - ]; then unset $var; else export $var=$v; fi
+  echo "== $var=$v"; timeout -k 10 120 python3 tools/conv_time.py 20 2>&1 | grep -v amdgpu.ids
 done > $out/conv_time.txt 2>&1
