@@ -226,6 +226,262 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Data gradient of the ConvTranspose stages: d a[p][c] = sum over the 9 taps (dy, dx) of dY[2 p + (dy, dx)][n] * W_t[n][c], fused
+// with the BN+ReLU backward of the input's norm (EPI_BNBWD of igemm.hip).  The stride-2 gather splits by the PARITY of the
+// gathered position into four sub-grids of dY, on each of which the taps form a box of 1, 2, 2 or 4 (exactly the forward
+// phases, mirrored): the kernel above with the halo addressed at stride 2, the four classes accumulated into one tile.
+struct CvdArgs {
+  ConvArgs c;
+  int tiles_y, tiles_x, ntn;
+  int tapidx[9];  // the launch's taps ordered by class: (even, even) 1, (even, odd) 2, (odd, even) 2, (odd, odd) 4
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  typedef typename TT<T>::vec V;
+  constexpr int SLOT = 8, BN = CP_BN, NT = BN / 32;
+  constexpr int NX = (CP_HH * CP_HW * (CP_CA / SLOT) + NTHREADS - 1) / NTHREADS;
+  const ConvArgs& a = g.c;
+  const Seg& sy = a.seg[0];  // dY (materialised gradient), 9 taps at stride 2
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Xs = smem;
+  unsigned char* Bs = smem + CP_X_BYTES;
+  int* rowpix = (int*)(smem + CP_MAIN);
+  double* red = (double*)(smem + CP_MAIN + BM * 4);  // [2][BN] fp64 (fits the forward kernel's partials area)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = lbid % g.ntn;
+  int tile = lbid / g.ntn;
+  const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
+  const int ty_i = tile % g.tiles_y;
+  const int b = tile / g.tiles_y;
+  const int y0 = ty_i * CP_TH, x0 = tx_i * CP_TW, n0 = ntile * BN;
+
+  if (tid < BM) {
+    const int y = y0 + (tid >> 4), x = x0 + (tid & 15);
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y) * a.Wout + x : -1;
+  }
+  if (tid < 2 * BN) red[tid] = 0.0;
+
+  const int cx = tid & 15, px0 = tid >> 4;
+  int xlds[NX];
+  unsigned xin = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int hp = px0 + 16 * i;
+    const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
+    if (hp < CP_HH * CP_HW) xin |= 1u << i;
+    xlds[i] = hy * CP_RP + hx * CP_PP + cx * 16;
+  }
+  const T* ysrc = (const T*)sy.src + cx * SLOT;
+  V rx[NX];
+  unsigned okx = 0;
+  // class (pa, pb): sub-grid pixel (y', x') = dY[2 y' + pa, 2 x' + pb]; its halo starts at (y0 - pa, x0 - pb)
+  auto issue_halo = [&](int pa, int pb, int grp, unsigned& ok) {
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hp = px0 + 16 * i;
+      const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
+      const int y = 2 * (y0 - pa + hy) + pa, x = 2 * (x0 - pb + hx) + pb;
+      if (hp < CP_HH * CP_HW && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws) ok |= 1u << i;
+      const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
+      rx[i] = *(const V*)(ysrc + pix * sy.ld + grp * CP_CA);
+    }
+  };
+  auto store_halo = [&](unsigned ok) {
+    V z;
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      if ((xin >> i) & 1) *(V*)(Xs + xlds[i]) = ((ok >> i) & 1) ? rx[i] : z;
+  };
+
+  const T* wp = (const T*)a.wpack;
+  const int cpt = sy.Cpad / 32;
+  V rb[2][2];
+  int blds[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = tid + NTHREADS * j, row = piece >> 2, slot = piece & 3;
+    blds[j] = row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+  }
+  auto issue_b = [&](int tap, int grp, int half) {
+    const int c0 = tap * cpt + grp * 4 + 2 * half;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const T* src = wp + ((size_t)(c0 + uu) * a.Npad + n0) * 32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb[uu][j] = *(const V*)(src + (size_t)(tid + NTHREADS * j) * SLOT);
+    }
+  };
+  auto store_b = [&](int buf) {
+    unsigned char* B = Bs + buf * CP_B_STAGE;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *(V*)(B + uu * (BN * 64) + blds[j]) = rb[uu][j];
+  };
+
+  const int abase = (2 * wave + (r >> 4)) * CP_RP + (r & 15) * CP_PP + h * 16;
+  const int bsw = (r >> 2) & 3;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  constexpr int NCV = BN / SLOT, RPP = NTHREADS / NCV, NIT = BM / RPP;
+  const int cv = tid % NCV, rr = tid / NCV;
+  const int n = n0 + cv * SLOT;
+  const bool colvalid = n < a.N;
+
+  const int ngrp = sy.C / CP_CA;
+  // flat walk: class -> channel group -> tap of the class -> half (2 chunks).  Stage s of the walk uses B buffer s & 1.
+  int buf = 0;
+  int first_tap = 0;
+  unsigned ok_cur = 0;
+  issue_halo(0, 0, 0, ok_cur);
+  issue_b(g.tapidx[0], 0, 0);
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pa = cls >> 1, pb = cls & 1;
+    const int ntap = (pa + 1) * (pb + 1);
+    for (int grp = 0; grp < ngrp; ++grp) {
+      store_halo(ok_cur);
+      // the next halo: next group of this class, or group 0 of the next class
+      const bool last_grp = grp + 1 == ngrp;
+      if (!(last_grp && cls == 3)) {
+        const int ncls = last_grp ? cls + 1 : cls;
+        issue_halo(ncls >> 1, ncls & 1, last_grp ? 0 : grp + 1, ok_cur);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt < ntap) {
+          const int tap = g.tapidx[first_tap + tt];
+          const int tw = sy.taps[tap];
+          const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
+          // halo position of the tap inside the class: row offset (dy - pa) / 2 + pa = (dy + pa) / 2, likewise the column
+          const int aoff = abase + ((dy + pa) >> 1) * CP_RP + ((dx + pb) >> 1) * CP_PP;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            store_b(buf);
+            __syncthreads();
+            // next stage's weights
+            if (half == 0) issue_b(tap, grp, 1);
+            else if (tt + 1 < ntap) issue_b(g.tapidx[first_tap + tt + 1], grp, 0);
+            else if (!last_grp) issue_b(g.tapidx[first_tap], grp + 1, 0);
+            else if (cls < 3) issue_b(g.tapidx[first_tap + ntap], 0, 0);
+            const unsigned char* B = Bs + buf * CP_B_STAGE;
+            const unsigned char* A = Xs + aoff + half * 128;
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+              for (int s = 0; s < 2; ++s) {
+                const V av = *(const V*)(A + uu * 64 + s * 32);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                  const V bv = *(const V*)(B + (uu * BN + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
+                  acc[t] = mma16(av, bv, acc[t]);
+                }
+              }
+            buf ^= 1;
+          }
+        }
+      }
+      __syncthreads();  // every wave is done with this halo image
+    }
+    first_tap += ntap;
+  }
+
+  // ---- epilogue: fused BN+ReLU backward (see igemm.hip / conv3.hip) ----
+  V xpre[NIT], gpre[NIT];
+  int ppre[NIT];
+  {
+    const T* bx = (const T*)a.bx;
+    const T* gold = (const T*)a.out;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pix = rowpix[rr + RPP * i];
+      ppre[i] = colvalid ? pix : -1;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) { xpre[i][e] = (T)0; gpre[i][e] = (T)0; }
+      if (ppre[i] >= 0) {
+        xpre[i] = *(const V*)(bx + (size_t)pix * a.ldbx + n);
+        if (a.accumulate) gpre[i] = *(const V*)(gold + (size_t)pix * a.ldo + n);
+      }
+    }
+  }
+  float* Cs = (float*)smem;  // fp32 staging (as igemm.hip): the ReLU mask and the reductions see the unrounded gradient
+  constexpr int FPITCH = BN + 4;
+  static_assert(BM * FPITCH * 4 <= CP_MAIN, "fp32 staging fits the operand images");
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+      Cs[row * FPITCH + 32 * t + r] = acc[t][i];
+    }
+  __syncthreads();
+  float s1[SLOT], s2[SLOT];
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  T* gout = (T*)a.out;
+  float sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+  if (colvalid) {
+    load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
+    load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    if (ppre[i] < 0) continue;
+    const int row = rr + RPP * i;
+    float av[SLOT], xf[SLOT], gf[SLOT];
+#pragma unroll
+    for (int e = 0; e < SLOT; e += 4) {
+      const f32x4 t4 = *(const f32x4*)(Cs + row * FPITCH + cv * SLOT + e);
+      av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
+    }
+    vec_to_f32<T>(xpre[i], xf);
+    vec_to_f32<T>(gpre[i], gf);  // zeros unless accumulating
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) {
+      const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+      s1[e] += dz;
+      s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+      gf[e] += sc[e] * dz;
+    }
+    *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
+  }
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) {
+#pragma unroll
+    for (int d = NCV; d < 64; d <<= 1) {
+      s1[i] += __shfl_xor(s1[i], d, 64);
+      s2[i] += __shfl_xor(s2[i], d, 64);
+    }
+  }
+  if (colvalid && lane < NCV) {
+#pragma unroll
+    for (int i = 0; i < SLOT; ++i) {
+      atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
+      atomicAdd(&red[BN + cv * SLOT + i], (double)s2[i]);
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < a.N) {
+    const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+    atomic_add_f64(a.red1 + rep + n0 + tid, red[tid]);
+    atomic_add_f64(a.red2 + rep + n0 + tid, red[BN + tid]);
+  }
+}
+
 static bool g_cvp = getenv("DMM_NO_CVP") == nullptr;
 void cvp_set_enabled(bool on) { g_cvp = on; }
 
@@ -244,10 +500,14 @@ static hipError_t launch_cvp_t(const CvpArgs& g, int nwg, hipStream_t st) {
   return hipGetLastError();
 }
 
+static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st);
+
 // Takes a forward launch (EPI_STORE) with one plain segment of a multiple of 128 BN+ReLU-normalised input channels whose 1, 2 or
 // 4 taps lie in a 2x2 box, a multiple of 128 padded output columns, 16-bit storage.  Returns hipErrorNotSupported otherwise.
 hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
-  if (!g_cvp || dtype == DT_F32 || epi != EPI_STORE || a.nseg != 1 || a.pool2) return hipErrorNotSupported;
+  if (!g_cvp || dtype == DT_F32) return hipErrorNotSupported;
+  if (epi == EPI_BNBWD) return launch_cvd(a, dtype, st);
+  if (epi != EPI_STORE || a.nseg != 1 || a.pool2) return hipErrorNotSupported;
   const Seg& x = a.seg[0];
   if (x.mode != G_PLAIN || x.istride != 1 || x.Hs != a.Ho || x.Ws != a.Wo || x.scale == nullptr || x.C % CP_CA || x.Cpad != x.C)
     return hipErrorNotSupported;
@@ -270,6 +530,45 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   const int nwg = a.B * g.tiles_y * g.tiles_x * g.ntn;
   if (dtype == DT_F16) return x.ntaps == 4 ? launch_cvp_t<f16, 4>(g, nwg, st) : (x.ntaps == 2 ? launch_cvp_t<f16, 2>(g, nwg, st) : launch_cvp_t<f16, 1>(g, nwg, st));
   return x.ntaps == 4 ? launch_cvp_t<bf16, 4>(g, nwg, st) : (x.ntaps == 2 ? launch_cvp_t<bf16, 2>(g, nwg, st) : launch_cvp_t<bf16, 1>(g, nwg, st));
+}
+
+template <typename T>
+static hipError_t launch_cvd_t(const CvdArgs& g, int nwg, hipStream_t st) {
+  auto kern = cvd_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), CP_LDS, st, g);
+  return hipGetLastError();
+}
+
+// The ConvTranspose data gradient: EPI_BNBWD, one plain segment (the materialised output gradient) gathered at stride 2 with the
+// nine taps (-1..1)^2, a multiple of 128 channels on both sides, gradient stored (not only reduced).
+static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
+  const Seg& y = a.seg[0];
+  if (a.nseg != 1 || a.pool2 || y.mode != G_PLAIN || y.istride != 2 || y.ntaps != 9 || y.scale != nullptr || y.q != nullptr) return hipErrorNotSupported;
+  if (y.Hs != 2 * a.Ho || y.Ws != 2 * a.Wo || y.C % CP_CA || y.Cpad != y.C) return hipErrorNotSupported;
+  if (a.Npad % CP_BN || a.out == nullptr || a.bx == nullptr || a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo) return hipErrorNotSupported;
+  CvdArgs g;
+  int cnt[4] = {0, 0, 0, 0};
+  const int base[4] = {0, 1, 3, 5};
+  for (int t = 0; t < 9; ++t) {
+    const int dy = (int)(signed char)(y.taps[t] & 0xff), dx = (int)(signed char)((y.taps[t] >> 8) & 0xff);
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return hipErrorNotSupported;
+    const int cls = (dy & 1) * 2 + (dx & 1);
+    if (cnt[cls] >= (cls == 0 ? 1 : (cls == 3 ? 4 : 2))) return hipErrorNotSupported;
+    g.tapidx[base[cls] + cnt[cls]++] = t;
+  }
+  if (g_cvp_dry) return hipSuccess;
+  g.c = a;
+  g.tiles_y = (a.Ho + CP_TH - 1) / CP_TH;
+  g.tiles_x = (a.Wo + CP_TW - 1) / CP_TW;
+  g.ntn = a.Npad / CP_BN;
+  const int nwg = a.B * g.tiles_y * g.tiles_x * g.ntn;
+  return dtype == DT_F16 ? launch_cvd_t<f16>(g, nwg, st) : launch_cvd_t<bf16>(g, nwg, st);
 }
 
 bool cvp_handles(const ConvArgs& a, int dtype, int epi) {

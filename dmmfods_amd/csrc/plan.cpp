@@ -698,7 +698,8 @@ struct Builder {
         const double srcb = (double)sb.B * sb.H * sb.W * sr.C * esz;
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
         const bool c3 = d.use_mfma && conv3_handles(a, dtype, EPI_BNBWD);
-        tag(o, ncls(c3 ? "conv3.bnbwd" : "igemm.bnbwd", pd.Npad, cb), short_name(c.wname), segf,
+        const bool cp = d.use_mfma && !c3 && cvp_handles(a, dtype, EPI_BNBWD);
+        tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : "igemm.bnbwd"), pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
       if (!raw) sb.ginit = true;
