@@ -234,15 +234,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
 struct CvdArgs {
   ConvArgs c;
   int tiles_y, tiles_x, ntn;
-  int tapidx[9];  // the launch's taps ordered by class: (even, even) 1, (even, odd) 2, (odd, even) 2, (odd, odd) 4
+  int tapidx[16];  // the launch's taps ordered by class (even, even), (even, odd), (odd, even), (odd, odd)
 };
 
-template <typename T>
+// CA = channels of dY per group (128, or 64 for the head); UP2 = the 16 merged taps (-1..2)^2 of the 3x3 convolution over a
+// nearest-x2 upsampled map (reference M:126-127; four taps in every class) instead of the ConvTranspose's nine.
+template <typename T, int CA, bool UP2>
 __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
-  static_assert(sizeof(T) == 2, "16-bit storage");
+  static_assert(sizeof(T) == 2 && (CA == 64 || CA == 128), "16-bit storage, 64 or 128 channels per group");
   typedef typename TT<T>::vec V;
   constexpr int SLOT = 8, BN = CP_BN, NT = BN / 32;
-  constexpr int NX = (CP_HH * CP_HW * (CP_CA / SLOT) + NTHREADS - 1) / NTHREADS;
+  constexpr int CSL = CA / SLOT;                       // slot columns of a halo pixel
+  constexpr int PSTEP = NTHREADS / CSL;                // halo pixels between a thread's slots
+  constexpr int NX = (CP_HH * CP_HW + PSTEP - 1) / PSTEP;
+  constexpr int PP = CA * 2 + 16;                      // pixel pitch (an odd number of 16-byte slots)
+  constexpr int RP = (CP_HW * PP + 255) / 256 * 256;
+  constexpr int HALVES = CA / 64;                      // stages (2 chunks) per tap and group
+  static_assert(CP_HH * RP <= CP_X_BYTES, "halo image fits");
   const ConvArgs& a = g.c;
   const Seg& sy = a.seg[0];  // dY (materialised gradient), 9 taps at stride 2
 
@@ -268,15 +276,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   }
   if (tid < 2 * BN) red[tid] = 0.0;
 
-  const int cx = tid & 15, px0 = tid >> 4;
+  const int cx = tid % CSL, px0 = tid / CSL;
   int xlds[NX];
   unsigned xin = 0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int hp = px0 + 16 * i;
+    const int hp = px0 + PSTEP * i;
     const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
     if (hp < CP_HH * CP_HW) xin |= 1u << i;
-    xlds[i] = hy * CP_RP + hx * CP_PP + cx * 16;
+    xlds[i] = hy * RP + hx * PP + cx * 16;
   }
   const T* ysrc = (const T*)sy.src + cx * SLOT;
   V rx[NX];
@@ -286,12 +294,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
     ok = 0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int hp = px0 + 16 * i;
+      const int hp = px0 + PSTEP * i;
       const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
       const int y = 2 * (y0 - pa + hy) + pa, x = 2 * (x0 - pb + hx) + pb;
       if (hp < CP_HH * CP_HW && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws) ok |= 1u << i;
       const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
-      rx[i] = *(const V*)(ysrc + pix * sy.ld + grp * CP_CA);
+      rx[i] = *(const V*)(ysrc + pix * sy.ld + grp * CA);
     }
   };
   auto store_halo = [&](unsigned ok) {
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
     blds[j] = row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
   }
   auto issue_b = [&](int tap, int grp, int half) {
-    const int c0 = tap * cpt + grp * 4 + 2 * half;
+    const int c0 = tap * cpt + grp * (CA / 32) + 2 * half;
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
       const T* src = wp + ((size_t)(c0 + uu) * a.Npad + n0) * 32;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
       for (int j = 0; j < 2; ++j) *(V*)(B + uu * (BN * 64) + blds[j]) = rb[uu][j];
   };
 
-  const int abase = (2 * wave + (r >> 4)) * CP_RP + (r & 15) * CP_PP + h * 16;
+  const int abase = (2 * wave + (r >> 4)) * RP + (r & 15) * PP + h * 16;
   const int bsw = (r >> 2) & 3;
   f32x16 acc[NT];
 #pragma unroll
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   const int n = n0 + cv * SLOT;
   const bool colvalid = n < a.N;
 
-  const int ngrp = sy.C / CP_CA;
+  const int ngrp = sy.C / CA;
   // flat walk: class -> channel group -> tap of the class -> half (2 chunks).  Stage s of the walk uses B buffer s & 1.
   int buf = 0;
   int first_tap = 0;
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
 #pragma unroll
   for (int cls = 0; cls < 4; ++cls) {
     const int pa = cls >> 1, pb = cls & 1;
-    const int ntap = (pa + 1) * (pb + 1);
+    const int ntap = UP2 ? 4 : (pa + 1) * (pb + 1);
     for (int grp = 0; grp < ngrp; ++grp) {
       store_halo(ok_cur);
       // the next halo: next group of this class, or group 0 of the next class
@@ -368,13 +376,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
           const int tw = sy.taps[tap];
           const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
           // halo position of the tap inside the class: row offset (dy - pa) / 2 + pa = (dy + pa) / 2, likewise the column
-          const int aoff = abase + ((dy + pa) >> 1) * CP_RP + ((dx + pb) >> 1) * CP_PP;
+          const int aoff = abase + ((dy + pa) >> 1) * RP + ((dx + pb) >> 1) * PP;
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
+          for (int half = 0; half < HALVES; ++half) {
             store_b(buf);
             __syncthreads();
             // next stage's weights
-            if (half == 0) issue_b(tap, grp, 1);
+            if (half + 1 < HALVES) issue_b(tap, grp, half + 1);
             else if (tt + 1 < ntap) issue_b(g.tapidx[first_tap + tt + 1], grp, 0);
             else if (!last_grp) issue_b(g.tapidx[first_tap], grp + 1, 0);
             else if (cls < 3) issue_b(g.tapidx[first_tap + ntap], 0, 0);
@@ -532,9 +540,9 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   return x.ntaps == 4 ? launch_cvp_t<bf16, 4>(g, nwg, st) : (x.ntaps == 2 ? launch_cvp_t<bf16, 2>(g, nwg, st) : launch_cvp_t<bf16, 1>(g, nwg, st));
 }
 
-template <typename T>
+template <typename T, int CA, bool UP2>
 static hipError_t launch_cvd_t(const CvdArgs& g, int nwg, hipStream_t st) {
-  auto kern = cvd_kernel<T>;
+  auto kern = cvd_kernel<T, CA, UP2>;
   static bool attr_done = false;
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
@@ -545,22 +553,26 @@ static hipError_t launch_cvd_t(const CvdArgs& g, int nwg, hipStream_t st) {
   return hipGetLastError();
 }
 
-// The ConvTranspose data gradient: EPI_BNBWD, one plain segment (the materialised output gradient) gathered at stride 2 with the
-// nine taps (-1..1)^2, a multiple of 128 channels on both sides, gradient stored (not only reduced).
+// Stride-2 data gradients with the fused BN+ReLU backward (EPI_BNBWD): one plain segment (the materialised output gradient), the
+// gradient stored (not only reduced), a multiple of 128 output columns, and either the ConvTranspose's nine taps (-1..1)^2 over
+// a multiple of 128 channels or the upsampled 3x3's sixteen merged taps (-1..2)^2 over 64 channels.
 static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
   const Seg& y = a.seg[0];
-  if (a.nseg != 1 || a.pool2 || y.mode != G_PLAIN || y.istride != 2 || y.ntaps != 9 || y.scale != nullptr || y.q != nullptr) return hipErrorNotSupported;
-  if (y.Hs != 2 * a.Ho || y.Ws != 2 * a.Wo || y.C % CP_CA || y.Cpad != y.C) return hipErrorNotSupported;
+  if (a.nseg != 1 || a.pool2 || y.mode != G_PLAIN || y.istride != 2 || y.scale != nullptr || y.q != nullptr) return hipErrorNotSupported;
+  const bool up2 = y.ntaps == 16;
+  if (!up2 && y.ntaps != 9) return hipErrorNotSupported;
+  if (y.Hs != 2 * a.Ho || y.Ws != 2 * a.Wo || y.Cpad != y.C || (up2 ? y.C != 64 : y.C % CP_CA != 0)) return hipErrorNotSupported;
   if (a.Npad % CP_BN || a.out == nullptr || a.bx == nullptr || a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo) return hipErrorNotSupported;
   CvdArgs g;
   int cnt[4] = {0, 0, 0, 0};
-  const int base[4] = {0, 1, 3, 5};
-  for (int t = 0; t < 9; ++t) {
+  const int base9[4] = {0, 1, 3, 5}, base16[4] = {0, 4, 8, 12};
+  for (int t = 0; t < y.ntaps; ++t) {
     const int dy = (int)(signed char)(y.taps[t] & 0xff), dx = (int)(signed char)((y.taps[t] >> 8) & 0xff);
-    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return hipErrorNotSupported;
+    if (dy < -1 || dx < -1 || dy > (up2 ? 2 : 1) || dx > (up2 ? 2 : 1)) return hipErrorNotSupported;
     const int cls = (dy & 1) * 2 + (dx & 1);
-    if (cnt[cls] >= (cls == 0 ? 1 : (cls == 3 ? 4 : 2))) return hipErrorNotSupported;
-    g.tapidx[base[cls] + cnt[cls]++] = t;
+    const int cap = up2 ? 4 : (cls == 0 ? 1 : (cls == 3 ? 4 : 2));
+    if (cnt[cls] >= cap) return hipErrorNotSupported;
+    g.tapidx[(up2 ? base16 : base9)[cls] + cnt[cls]++] = t;
   }
   if (g_cvp_dry) return hipSuccess;
   g.c = a;
@@ -568,7 +580,8 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
   g.tiles_x = (a.Wo + CP_TW - 1) / CP_TW;
   g.ntn = a.Npad / CP_BN;
   const int nwg = a.B * g.tiles_y * g.tiles_x * g.ntn;
-  return dtype == DT_F16 ? launch_cvd_t<f16>(g, nwg, st) : launch_cvd_t<bf16>(g, nwg, st);
+  if (up2) return dtype == DT_F16 ? launch_cvd_t<f16, 64, true>(g, nwg, st) : launch_cvd_t<bf16, 64, true>(g, nwg, st);
+  return dtype == DT_F16 ? launch_cvd_t<f16, 128, false>(g, nwg, st) : launch_cvd_t<bf16, 128, false>(g, nwg, st);
 }
 
 bool cvp_handles(const ConvArgs& a, int dtype, int epi) {
