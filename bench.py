@@ -116,7 +116,9 @@ def measured_traffic(cls, workload):
             continue
         if (d.get("config"), d.get("batch"), d.get("dtype")) != workload:
             continue
-        e = d.get("classes", {}).get(cls)
+        # rocprof sees kernel names, not the plan's labels: the generic weight-gradient kernel (normal and transposed form) is one
+        # class there ("wgrad*.nN"); it stands for the plan's "wgrad.nN" when the launch counts of the step agree
+        e = d.get("classes", {}).get(cls) or d.get("classes", {}).get(cls.replace("wgrad.", "wgrad*."))
         if e:
             return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
     return None

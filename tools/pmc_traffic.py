@@ -27,6 +27,12 @@ def classify(name):
         return "wg3.n128"
     if "wgp_kernel" in name:
         return "wgp"
+    if "wg5_kernel" in name:
+        return "wg5.n64"
+    if "cvp_kernel" in name:
+        return "cvp.store.n128"
+    if "cvd_kernel" in name:
+        return "cvp.bnbwd.n128"
     m = re.search(r"halo_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"igemm.{EPI.get(m.group(2), m.group(2))}.n{m.group(1)}"
