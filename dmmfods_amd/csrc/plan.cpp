@@ -722,7 +722,7 @@ struct Builder {
     a.scale = bns[p.bn].scale; a.shift = bns[p.bn].shift;
     a.out = (void*)xat(p.obuf, p.och0); a.ldo = ob.ld; a.Hp = ob.H; a.Wp = ob.W;
     a.argmax = p.argmax;
-    a.stat_sum = ob.ssum + p.och0; a.stat_sq = ob.ssq + p.och0;
+    a.stat_sum = ob.ssum + p.och0; a.stat_sq = ob.ssq + p.och0; a.stat_stride = ob.ld;
     tag(o, "maxpool.fwd", "pool0", 0, ((double)yb.B * yb.H * yb.W + (double)ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
   }
   void emit_pool_bwd(PoolRec& p) {
@@ -740,7 +740,7 @@ struct Builder {
     a.argmax = p.argmax;
     a.gy0 = yb.g;
     a.mean = bns[p.bn].mean; a.invstd = bns[p.bn].invstd;
-    a.red1 = bns[p.bn].red1; a.red2 = bns[p.bn].red2;
+    a.red1 = bns[p.bn].red1; a.red2 = bns[p.bn].red2; a.stat_stride = bns[p.bn].cp;
     tag(o, "maxpool.bwd", "pool0", 0, (2.0 * yb.B * yb.H * yb.W + 2.0 * ob.B * ob.H * ob.W) * p.C * esz + (double)ob.B * ob.H * ob.W * p.C);
     yb.ginit = true;
     emit_bn_bwd_finalize(p.bn);

@@ -64,6 +64,7 @@ struct MaxpoolArgs {
   unsigned char* argmax;  // (B, Hp, Wp, C)
   double* stat_sum;
   double* stat_sq;
+  int stat_stride;  // doubles between the STAT_REPS replicas of sum / sq (0: a single copy)
 };
 
 struct MaxpoolBwdArgs {
@@ -84,6 +85,7 @@ struct MaxpoolBwdArgs {
   void* gy0;  // (B, H0, W0, ld0): s * dz0
   double* red1;
   double* red2;
+  int stat_stride;  // doubles between the STAT_REPS replicas of red1 / red2 (0: a single copy)
 };
 
 struct BceArgs {

@@ -137,7 +137,7 @@ hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st) {
 // Block-wide per-channel reduction helper: NCV slot columns x (256/NCV) row lanes.
 template <int SLOT>
 __device__ __forceinline__ void block_channel_reduce(double* red, int C, int cbase, const double (&s1)[SLOT],
-                                                     const double (&s2)[SLOT], double* d1, double* d2) {
+                                                     const double (&s2)[SLOT], double* d1, double* d2, int stat_stride = 0) {
   // red: 2*C doubles, zeroed and synchronised by the caller
 #pragma unroll
   for (int i = 0; i < SLOT; ++i) {
@@ -145,9 +145,12 @@ __device__ __forceinline__ void block_channel_reduce(double* red, int C, int cba
     atomicAdd(&red[C + cbase + i], s2[i]);
   }
   __syncthreads();
+  // thousands of workgroups adding to the same C addresses serialise in the L2 atomic unit: one replica per XCD (summed by the
+  // finalize kernels), as in igemm.hip
+  const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * stat_stride;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomic_add_f64(d1 + c, red[c]);
-    atomic_add_f64(d2 + c, red[C + c]);
+    atomic_add_f64(d1 + rep + c, red[c]);
+    atomic_add_f64(d2 + rep + c, red[C + c]);
   }
 }
 
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxpoolArgs a) {
       else *(unsigned*)(a.argmax + (size_t)p * a.C + c) = (unsigned)packed;
     }
   }
-  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.stat_sum, a.stat_sq);
+  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.stat_sum, a.stat_sq, a.stat_stride);
 }
 
 hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st) {
@@ -222,7 +225,7 @@ hipError_t launch_maxpool_fwd(const MaxpoolArgs& a, int dtype, hipStream_t st) {
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.Hp * a.Wp;
   int grid = (npix + rpb - 1) / rpb;
-  if (grid > 8192) grid = 8192;
+  if (grid > 2048) grid = 2048;  // 8 workgroups per CU: every workgroup ends with 2 C fp64 atomics
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, a);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
       *(V*)(gy0 + (size_t)p * a.ld0 + c) = f32_to_vec<T>(o);
     }
   }
-  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.red1, a.red2);
+  block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.red1, a.red2, a.stat_stride);
 }
 
 hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st) {
@@ -309,7 +312,7 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.H0 * a.W0;
   int grid = (npix + rpb - 1) / rpb;
-  if (grid > 8192) grid = 8192;
+  if (grid > 2048) grid = 2048;  // 8 workgroups per CU: every workgroup ends with 2 C fp64 atomics
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, a);
