@@ -30,9 +30,10 @@ constexpr int CP_X_BYTES = CP_HH * CP_RP;       // 43 KB
 constexpr int CP_B_STAGE = 2 * CP_BN * 64;      // 16 KB: two 64-byte chunks of K for 128 columns
 constexpr int CP_MAIN = CP_X_BYTES + 2 * CP_B_STAGE;
 constexpr int CP_CPITCH = CP_BN + 8;            // staging pitch (elements of T)
-constexpr int CP_EXTRA = BM * 4 + 4 * 2 * CP_BN * 4;  // rowpix + per-wave column partials
+constexpr int CP_EXTRA = BM * 4;                 // rowpix (the epilogue's column partials / fp64 sums overlay the dead operand images)
 constexpr int CP_LDS = CP_MAIN + CP_EXTRA;
-static_assert(BM * CP_CPITCH * 2 <= CP_MAIN, "staging fits the operand images");
+static_assert(BM * (CP_BN + 4) * 4 + 4 * 2 * CP_BN * 4 <= CP_MAIN, "fp32 staging + partials fit the operand images");
+constexpr int CP_PART = BM * (CP_BN + 4) * 4;   // offset of the partials inside the dead images (behind the largest staging form)
 static_assert(2 * CP_LDS <= 160 * 1024, "two workgroups per CU");
 
 struct CvpArgs {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   unsigned char* Xs = smem;
   unsigned char* Bs = smem + CP_X_BYTES;
   int* rowpix = (int*)(smem + CP_MAIN);
-  float* wpart = (float*)(smem + CP_MAIN + BM * 4);  // [wave][2][BN]
+  float* wpart = (float*)(smem + CP_PART);  // [wave][2][BN]; only touched after the K loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -109,28 +110,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   // ---- weights: a stage = chunks (c0, c0 + 1) x 128 columns = 2 x 8 KB contiguous; thread -> pieces tid, tid + 256 of each ----
   const T* wp = (const T*)a.wpack;
   const int cpt = sx.Cpad / 32;  // chunks per tap
-  V rb[2][2];
+  // two register sets, filled two stages ahead: a stage's MFMAs are shorter than an L2 round trip.  Every load is issued
+  // unconditionally (past the end: a valid chunk again) so that the compiler's counted waits leave the other set in flight.
+  struct BRegs { V v[2][2]; };
+  BRegs rb0, rb1;
   int blds[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int piece = tid + NTHREADS * j, row = piece >> 2, slot = piece & 3;
     blds[j] = row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
   }
-  auto issue_b = [&](int grp, int st) {
-    const int c0 = (st >> 1) * cpt + grp * 4 + 2 * (st & 1);
+  const int ngrp = sx.C / CP_CA;
+  auto issue_b = [&](BRegs& R, int grp, int st) {  // stage st of group grp; st may run past the group (the next group's stages)
+    int gq = grp + (st >= NST ? 1 : 0);
+    const int sq = st >= NST ? st - NST : st;
+    gq = min(gq, ngrp - 1);
+    const int c0 = (sq >> 1) * cpt + gq * 4 + 2 * (sq & 1);
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
       const T* src = wp + ((size_t)(c0 + uu) * a.Npad + n0) * 32;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rb[uu][j] = *(const V*)(src + (size_t)(tid + NTHREADS * j) * SLOT);
+      for (int j = 0; j < 2; ++j) R.v[uu][j] = *(const V*)(src + (size_t)(tid + NTHREADS * j) * SLOT);
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](const BRegs& R, int buf) {
     unsigned char* B = Bs + buf * CP_B_STAGE;
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) *(V*)(B + uu * (BN * 64) + blds[j]) = rb[uu][j];
+      for (int j = 0; j < 2; ++j) *(V*)(B + uu * (BN * 64) + blds[j]) = R.v[uu][j];
   };
 
   // ---- fragments: wave w owns tile rows 2w, 2w + 1 (32 pixels) x 128 columns ----
@@ -149,20 +157,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  const int ngrp = sx.C / CP_CA;
   issue_halo(0);
-  issue_b(0, 0);
-  int buf = 0;
+  issue_b(rb0, 0, 0);
+  issue_b(rb1, 0, 1);
   for (int grp = 0; grp < ngrp; ++grp) {
     store_halo(grp);  // (the barrier that ended the previous group made the image free)
-    if (grp + 1 < ngrp) issue_halo(grp + 1);
+    issue_halo(min(grp + 1, ngrp - 1));
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      store_b(buf);
+      BRegs& R = (st & 1) ? rb1 : rb0;  // NST is even: stage parity = register set = LDS buffer, across groups as well
+      store_b(R, st & 1);
       __syncthreads();  // this stage's weights (and, in the first stage of a group, the halo image) are complete
-      if (st + 1 < NST) issue_b(grp, st + 1);
-      else if (grp + 1 < ngrp) issue_b(grp + 1, 0);
-      const unsigned char* B = Bs + buf * CP_B_STAGE;
+      issue_b(R, grp, st + 2);
+      const unsigned char* B = Bs + (st & 1) * CP_B_STAGE;
       const unsigned char* A = Xs + aoff[st >> 1] + (st & 1) * 128;
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu)
@@ -175,7 +182,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
             acc[t] = mma16(av, bv, acc[t]);
           }
         }
-      buf ^= 1;
     }
     __syncthreads();  // every wave is done with the halo image of this group
   }
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   unsigned char* Xs = smem;
   unsigned char* Bs = smem + CP_X_BYTES;
   int* rowpix = (int*)(smem + CP_MAIN);
-  double* red = (double*)(smem + CP_MAIN + BM * 4);  // [2][BN] fp64 (fits the forward kernel's partials area)
+  double* red = (double*)(smem + CP_PART);  // [2][BN] fp64; zeroed after the K loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -274,8 +280,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
     const int y = y0 + (tid >> 4), x = x0 + (tid & 15);
     rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y) * a.Wout + x : -1;
   }
-  if (tid < 2 * BN) red[tid] = 0.0;
-
   const int cx = tid % CSL, px0 = tid / CSL;
   int xlds[NX];
   unsigned xin = 0;
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
       }
     }
   }
+  if (tid < 2 * BN) red[tid] = 0.0;  // (the K loop ended with a barrier: the images are dead)
   float* Cs = (float*)smem;  // fp32 staging (as igemm.hip): the ReLU mask and the reductions see the unrounded gradient
   constexpr int FPITCH = BN + 4;
   static_assert(BM * FPITCH * 4 <= CP_MAIN, "fp32 staging fits the operand images");
