@@ -440,6 +440,7 @@ static hipError_t launch_c3_type(const Conv3Args& g, int epi, int pro, int cs, i
     if (cs == 8 && nt == 1 && pro == 0) return launch_c3<T, 8, 2, -1, 1, 1, 2, EPI_BNBWD, 0>(g, st);              // refine0 -> raw input
     if (cs == 8 && nt == 1 && pro == 2) return launch_c3<T, 8, 2, -1, 1, 1, 2, EPI_BNBWD, 2>(g, st);
   }
+  if (epi == EPI_STORE && cs == 0 && tspan == 6 && tstr == 2 && pro == 0 && nt == 2) return launch_c3<T, 0, 0, 6, 2, 2, 2, EPI_STORE, 0>(g, st);  // stem conv0 (7x7 stride 2)
   if (epi == EPI_BNBWD && cs == 0 && tspan == 4 && tstr == 1 && pro == 0) {                                          // refine1 dgrad (5x5)
     if (nt == 2) return launch_c3<T, 0, 0, 4, 1, 2, 2, EPI_BNBWD, 0>(g, st);
     if (nt == 1) return launch_c3<T, 0, 0, 4, 1, 1, 2, EPI_BNBWD, 0>(g, st);
@@ -456,8 +457,8 @@ static bool tap_box(const Seg& sg, int& dymin, int& dxmin, int& span) {
     dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
   }
   span = dymax - dymin;
-  if (span < 0 || span > 4 || dxmax - dxmin != span || sg.ntaps != (span + 1) * (span + 1)) return false;
-  bool seen[25] = {false};
+  if (span < 0 || span > 6 || dxmax - dxmin != span || sg.ntaps != (span + 1) * (span + 1)) return false;
+  bool seen[49] = {false};
   for (int t = 0; t < sg.ntaps; ++t) {  // every offset of the box exactly once, in any order
     const int dy = (int)(signed char)(sg.taps[t] & 0xff) - dymin, dx = (int)(signed char)((sg.taps[t] >> 8) & 0xff) - dxmin;
     if (seen[dy * (span + 1) + dx]) return false;
@@ -480,7 +481,10 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
     return s1.mode == G_PLAIN && s1.istride == stride && s1.C == 8 && s1.Cpad == 8 && s1.Hs == stride * a.Ho && s1.Ws == stride * a.Wo &&
            s1.q == nullptr && tap_box(s1, g.dymin1, g.dxmin1, tspan);
   };
-  if (a.nseg == 1 && sg.C == 8) {   // thin segment only: the logits gradient under the 5x5 head convolution
+  if (a.nseg == 1 && sg.C == 8 && sg.istride == 2) {  // thin segment only, stride 2: the stem's 7x7 convolution over the raw input
+    tstr = 2;
+    if (epi != EPI_STORE || !thin_ok(sg, 2) || tspan != 6 || sg.scale != nullptr) return hipErrorNotSupported;
+  } else if (a.nseg == 1 && sg.C == 8) {   // thin segment only: the logits gradient under the 5x5 head convolution
     if (!thin_ok(sg, 1) || tspan != 4 || sg.scale != nullptr) return hipErrorNotSupported;
   } else {
     if (sg.mode != G_PLAIN || sg.istride != 1 || sg.C % 32 || sg.Cpad != sg.C || sg.Hs != a.Ho || sg.Ws != a.Wo) return hipErrorNotSupported;
@@ -492,6 +496,7 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
     }
   }
   if (a.nseg == 1 && (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo)) return hipErrorNotSupported;
+  if (cs == 0 && tspan == 6 && a.Npad != 64) return hipErrorNotSupported;
   const int pro = sg.scale ? 1 : (sg.q ? 2 : 0);
   if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
   g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
