@@ -1,0 +1,350 @@
+// Backward of the dense layers' 1x1 bottleneck convolution (torchvision _DenseLayer.conv1: C_in -> 128 channels behind norm1 + ReLU;
+// reference call sites M:85-92, M:169-176) - data gradient AND weight gradient in one pass.  gfx950, 16-bit storage types.
+//
+//   G   = g + q + r*y            the bottleneck's effective gradient (128 channels), read ONCE
+//   dX  = G W                    data gradient, fused with norm1's backward:  dz = dX * [bn1(x) > 0],  g_x (+)= s*dz,  sum dz, sum dz*xhat
+//   dW  = G^T relu(bn1(x))       weight gradient, accumulated in registers over the workgroup's rows
+// The two generic kernels (igemm.hip EPI_BNBWD on the main stream, wgrad.hip on the side stream) each read G, y and x: three
+// tensors of the layer twice, 37 % of the pair's HBM traffic on a pair that is HBM-bound (43 flop per byte).  Here a persistent
+// workgroup owns a 128-channel slice of C_in and a range of 64-pixel row tiles; per tile x and G go to LDS once (prologues once per
+// element), the data-gradient GEMM reads G rows and the resident weight slice, the weight-gradient GEMM reads both images with
+// the transposing read ds_read_b64_tr_b16 (contraction over pixels, as wgrad.hip), the fp32 tile is staged over the dead images and
+// finished in the slot layout the loads came in - the raw x of the ReLU mask is still in the loading thread's registers.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "gather.h"
+#include "pointwise.h"
+
+namespace dmm {
+
+constexpr int B1_TM = 64;                       // pixels per tile
+constexpr int B1_NB = 128;                      // bottleneck channels (K of the data gradient, N of the weight gradient)
+constexpr int B1_CT = 128;                      // input channels per workgroup
+constexpr int B1_IMG = B1_TM * 256;             // 16 KB: 64 rows x 256 bytes, 16-byte slot XOR-ed with (row & 15)
+constexpr int B1_W = 4 * B1_CT * 64;            // 32 KB: the weight slice [chunk][c][32 n], igemm's B image
+constexpr int B1_STAGE = B1_TM * B1_CT * 4;     // fp32 tile over the two operand images
+static_assert(B1_STAGE == 2 * B1_IMG, "staging aliases the operand images exactly");
+constexpr int B1_LDS = 2 * B1_IMG + B1_W + 2 * B1_CT * 8 + 6 * B1_CT * 4;  // + fp64 reduction scratch + per-channel constants
+
+typedef unsigned b1_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ b1_u32x2 b1_tr16(const unsigned char* p) {
+  typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(p));
+  return __builtin_bit_cast(b1_u32x2, r);
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::vec b1_frag(const b1_u32x2& lo, const b1_u32x2& hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(typename TT<T>::vec, v);
+}
+
+// PQ = prologue of G: 0 none (materialised gradient), 2 effective gradient.  ACC = the gradient of x is accumulated (an earlier
+// consumer of the block buffer has already written it).
+template <typename T, int PQ, bool ACC>
+__global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  typedef typename TT<T>::vec V;
+  constexpr int SLOT = 8;
+  constexpr int NL = B1_TM * 16 / NTHREADS;  // 4 slots per thread and operand
+  const ConvArgs& a = g.c;
+  const Seg& sg = a.seg[0];  // G: the bottleneck gradient (+ y, q, r)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ai = smem;                 // relu(bn(x)) [64 px][128 c]
+  unsigned char* Gi = smem + B1_IMG;        // G [64 px][128 n]
+  unsigned char* Wi = smem + 2 * B1_IMG;    // weight slice
+  double* red = (double*)(smem + 2 * B1_IMG + B1_W);
+  float* kc = (float*)(smem + 2 * B1_IMG + B1_W + 2 * B1_CT * 8);  // [scale | shift | mean | invstd | q | r] x 128
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ct = blockIdx.x % g.nct, split = blockIdx.x / g.nct;
+  const int c0 = ct * B1_CT;
+  const int t_beg = split * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
+  if (t_beg >= t_end) return;
+
+  // ---- this thread's slots: column cs (8 channels), rows p0 + 16 i of the tile; the same mapping loads and finishes a tile ----
+  const int cs = tid & 15, p0 = tid >> 4;
+  const int cx = c0 + cs * SLOT;          // input channel of the x / gradient slot
+  const bool cvalid = cx < a.N;
+  // the per-channel constants - norm1's scale / shift / mean / invstd of this channel slice, q / r of G - live in LDS and are read
+  // where a tile needs them: held in registers across the MFMA phases they spill the accumulators
+  if (tid < B1_CT) {
+    const int c = c0 + tid;
+    const bool v = c < a.N;
+    kc[tid] = v ? a.bscale[c] : 0.f; kc[B1_CT + tid] = v ? a.bshift[c] : 0.f;
+    kc[2 * B1_CT + tid] = v ? a.bmean[c] : 0.f; kc[3 * B1_CT + tid] = v ? a.binvstd[c] : 0.f;
+    kc[4 * B1_CT + tid] = PQ == 2 ? sg.q[tid] : 0.f; kc[5 * B1_CT + tid] = PQ == 2 ? sg.r[tid] : 0.f;
+  }
+  const T* xsrc = (const T*)a.bx + (cvalid ? cx : 0);
+  const T* gsrc = (const T*)sg.src + cs * SLOT;
+  const T* ysrc = (const T*)sg.src2 + cs * SLOT;
+  T* gout = (T*)a.out + (cvalid ? cx : 0);
+  int lds[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int p = p0 + 16 * i;
+    lds[i] = p * 256 + ((cs ^ (p & 15)) << 4);
+  }
+
+  // ---- the weight slice, once: chunks of 32 bottleneck channels x 128 input channels (igemm's B image, XOR swizzle) ----
+  {
+    const T* wp = (const T*)a.wpack;
+#pragma unroll
+    for (int j = 0; j < B1_W / 16 / NTHREADS; ++j) {
+      const int piece = tid + NTHREADS * j;           // 16-byte piece of the slice: (chunk, row c, slot)
+      const int chunk = piece >> 9, rowc = (piece >> 2) & 127, slot = piece & 3;
+      const int c = c0 + rowc;
+      V v;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) v[e] = (T)0;
+      if (c < a.Npad) v = *(const V*)(wp + ((size_t)chunk * a.Npad + c) * 32 + slot * SLOT);
+      *(V*)(Wi + chunk * (B1_CT * 64) + rowc * 64 + ((slot ^ ((rowc >> 2) & 3)) << 4)) = v;
+    }
+  }
+  if (tid < 2 * B1_CT) red[tid] = 0.0;
+  __syncthreads();  // constants readable by the first tile's prologues
+
+  V rx[NL], rg[NL], ry[PQ == 2 ? NL : 1];
+  unsigned okp = 0;  // row validity of the slots in flight
+  auto issue = [&](int tile) {
+    okp = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {  // branch-free: clamped rows, dropped at the write
+      const int m = tile * B1_TM + p0 + 16 * i;
+      if (m < a.M) okp |= 1u << i;
+      const size_t mm = (size_t)min(m, a.M - 1);
+      rx[i] = *(const V*)(xsrc + mm * a.ldbx);
+      rg[i] = *(const V*)(gsrc + mm * sg.ld);
+      if constexpr (PQ == 2) ry[i] = *(const V*)(ysrc + mm * sg.ld2);
+    }
+  };
+
+  // ---- fragments ----
+  // data gradient: wave w -> pixel rows 32 (w & 1) .., input channels 64 (w >> 1) ..  (2 tiles of 32 columns)
+  const int dpx = 32 * (wave & 1) + r;
+  const int dgoff = dpx * 256;            // + ((slot ^ (dpx & 15)) << 4) per k-step
+  const int dkey = dpx & 15;
+  const int dcb = 64 * (wave >> 1);       // first column of this wave's half
+  const int bsw = (r >> 2) & 3;
+  // weight gradient: wave w -> input channels 32 w .. (rows of dP chunk c0 / 32 + w), all 128 bottleneck channels (4 tiles)
+  const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+  const int arow = 8 * (tg >> 1) + tq;    // pixel row of the first transposing read; the second is 4 rows further
+  auto tr_off = [&](int px, int colbyte) { return px * 256 + ((((colbyte >> 4) ^ (px & 15)) << 4) | (colbyte & 15)); };
+  // a k-step further down the tile is 16 rows = 4096 bytes further: (row & 15), the swizzle key, does not change
+  const int acolb = (32 * wave + 16 * (tg & 1) + 4 * tp) * 2;
+  const int aoff1 = tr_off(arow, acolb), aoff2 = tr_off(arow + 4, acolb);
+  int goff1[4], goff2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cb = (32 * j + 16 * (tg & 1) + 4 * tp) * 2;
+    goff1[j] = tr_off(arow, cb); goff2[j] = tr_off(arow + 4, cb);
+  }
+
+  f32x16 accw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accw[j][i] = 0.f;
+
+  issue(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    // ---- operands to LDS (prologues once per element); raw x and the old gradient stay in registers for the epilogue ----
+    V xraw[NL], gold[ACC ? NL : 1];  // (the old gradient is requested behind the MFMAs: it lands while the tile is staged)
+    const unsigned ok = okp;
+    {
+      SlotK<SLOT> kx, kg;
+      kx.k0 = load_fv<SLOT>(kc + cs * SLOT); kx.k1 = load_fv<SLOT>(kc + B1_CT + cs * SLOT); kx.k2 = 0.f; kx.k3 = 0.f;
+      kg.k0 = 0.f; kg.k1 = 0.f; kg.k2 = 0.f; kg.k3 = 0.f;
+      if (PQ == 2) { kg.k0 = load_fv<SLOT>(kc + 4 * B1_CT + cs * SLOT); kg.k1 = load_fv<SLOT>(kc + 5 * B1_CT + cs * SLOT); }
+      V z;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        xraw[i] = rx[i];
+        const bool v = ((ok >> i) & 1) != 0;
+        *(V*)(Ai + lds[i]) = (v && cvalid) ? bn_relu_slot(rx[i], kx) : z;
+        V gv = rg[i];
+        if constexpr (PQ == 2) gv = eff_grad_slot(rg[i], ry[i], kg);
+        *(V*)(Gi + lds[i]) = v ? gv : z;
+      }
+    }
+    __syncthreads();  // images (and, the first time, the weight slice) complete
+    if (tile + 1 < t_end) issue(tile + 1);
+
+    // ---- data gradient: dX[64 px][128 c] = G W ----
+    f32x16 accd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accd[t][i] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int slot = ch * 4 + 2 * s + h;
+        const V av = *(const V*)(Gi + dgoff + ((slot ^ dkey) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const V bv = *(const V*)(Wi + ch * (B1_CT * 64) + (dcb + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
+          accd[t] = mma16(av, bv, accd[t]);
+        }
+      }
+    // ---- weight gradient: dP[c][n] += sum over the tile's pixels G[p][n] a[p][c] ----
+#pragma unroll
+    for (int ms = 0; ms < B1_TM / 16; ++ms) {
+      const V af = b1_frag<T>(b1_tr16(Ai + aoff1 + ms * 4096), b1_tr16(Ai + aoff2 + ms * 4096));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const V gf = b1_frag<T>(b1_tr16(Gi + goff1[j] + ms * 4096), b1_tr16(Gi + goff2[j] + ms * 4096));
+        accw[j] = mma16(gf, af, accw[j]);  // rows: bottleneck channel n, columns: input channel c
+      }
+    }
+    if constexpr (ACC) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const size_t mm = (size_t)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
+        gold[i] = *(const V*)(gout + mm * a.ldo);
+      }
+    }
+    __syncthreads();  // all waves done with the images: stage the data-gradient tile over them
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * (wave & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+        Cs[row * B1_CT + dcb + 32 * t + r] = accd[t][i];
+      }
+    __syncthreads();
+    // ---- norm1 backward in the slot layout of the loads ----
+    float s1[SLOT], s2[SLOT];
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (cvalid) {
+      float sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+      load_f32s<SLOT>(kc + cs * SLOT, sc); load_f32s<SLOT>(kc + B1_CT + cs * SLOT, sh);
+      load_f32s<SLOT>(kc + 2 * B1_CT + cs * SLOT, mu); load_f32s<SLOT>(kc + 3 * B1_CT + cs * SLOT, is);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (!((ok >> i) & 1)) continue;
+        const int p = p0 + 16 * i;
+        float av[SLOT], xf[SLOT], gf[SLOT];
+#pragma unroll
+        for (int e = 0; e < SLOT; e += 4) {
+          const f32x4 t4 = *(const f32x4*)(Cs + p * B1_CT + cs * SLOT + e);
+          av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
+        }
+        vec_to_f32<T>(xraw[i], xf);
+        if constexpr (ACC) vec_to_f32<T>(gold[i], gf);
+#pragma unroll
+        for (int e = 0; e < SLOT; ++e) {
+          const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+          s1[e] += dz;
+          s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+          gf[e] = (ACC ? gf[e] : 0.f) + sc[e] * dz;
+        }
+        const size_t m = (size_t)tile * B1_TM + p;
+        *(V*)(gout + m * a.ldo) = f32_to_vec<T>(gf);
+      }
+    }
+    // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column, then fp64 in LDS
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+      s2[e] += __shfl_xor(s2[e], 16, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
+    }
+    if (cvalid && lane < 16) {
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) {
+        atomicAdd(&red[cs * SLOT + e], (double)s1[e]);
+        atomicAdd(&red[B1_CT + cs * SLOT + e], (double)s2[e]);
+      }
+    }
+    __syncthreads();  // staging read: the next tile's images may be written
+  }
+
+  // ---- results of the walk: per-channel sums (one fp64 atomic per channel and workgroup), the weight-gradient slice ----
+  if (tid < B1_CT && c0 + tid < a.N) {
+    const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+    atomic_add_f64(a.red1 + rep + c0 + tid, red[tid]);
+    atomic_add_f64(a.red2 + rep + c0 + tid, red[B1_CT + tid]);
+  }
+  const int c = c0 + 32 * wave + r;
+  if (c < g.wC) {
+    const size_t chunk = (size_t)(c0 / 32 + wave);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h;
+        atomic_add_f32(g.dpack + (chunk * g.dNpad + n) * 32 + r, accw[j][i]);
+      }
+  }
+}
+
+static bool g_bw1 = getenv("DMM_NO_BW1") == nullptr;
+void bw1_set_enabled(bool on) { g_bw1 = on; }
+bool bw1_enabled() { return g_bw1; }
+
+template <typename T, int PQ, bool ACC>
+static hipError_t launch_bw1_t(const Bw1Args& g, int nwg, hipStream_t st) {
+  auto kern = bw1_kernel<T, PQ, ACC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), B1_LDS, st, g);
+  return hipGetLastError();
+}
+
+// Do these two launches - the weight gradient `w` (normal form) and the data gradient `d` (EPI_BNBWD) of one convolution - form
+// the pair this kernel fuses?  1x1, unit stride, 128 output channels, the same x / norm and the same gradient operand on both.
+bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype) {
+  if (!g_bw1 || dtype == DT_F32 || w.nseg != 1 || d.nseg != 1 || d.pool2) return false;
+  const Seg& wx = w.seg[0];   // x with norm1's scale / shift
+  const Seg& wg = w.dy;       // G
+  const Seg& dg = d.seg[0];   // G again
+  if (wx.mode != G_PLAIN || wx.istride != 1 || wx.ntaps != 1 || wx.taps[0] != 0 || wx.scale == nullptr || wx.C % 32) return false;
+  if (wg.mode != G_PLAIN || wg.istride != 1 || wg.ntaps != 1 || wg.taps[0] != 0 || wg.scale != nullptr || wg.C != B1_NB) return false;
+  if (dg.mode != G_PLAIN || dg.istride != 1 || dg.ntaps != 1 || dg.taps[0] != 0 || dg.scale != nullptr || dg.C != B1_NB || dg.Cpad != B1_NB) return false;
+  if (dg.src != wg.src || dg.ld != wg.ld || dg.q != wg.q || dg.src2 != wg.src2) return false;
+  if (w.N != B1_NB || w.Npad != B1_NB || w.M != d.M || d.N != wx.C || d.Npad % 32) return false;
+  if (d.bx != wx.src || d.ldbx != wx.ld || d.bscale != wx.scale || d.bshift != wx.shift) return false;
+  if (d.out == nullptr || d.ostride != 1 || d.Hout != d.Ho || d.Wout != d.Wo || wx.Hs != d.Ho || wx.Ws != d.Wo) return false;
+  return true;
+}
+
+hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
+  Bw1Args g = g0;
+  const ConvArgs& a = g.c;
+  if (a.M <= 0) return hipSuccess;
+  g.nct = (a.N + B1_CT - 1) / B1_CT;
+  g.ntiles = (a.M + B1_TM - 1) / B1_TM;
+  static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
+                              return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  static const int per_cu = getenv("DMM_BW1_PER_CU") ? atoi(getenv("DMM_BW1_PER_CU")) : 2;
+  // every workgroup ends with 64 KB of fp32 atomics and a tile is ~2 us of work: at least 4 tiles per workgroup
+  int nsplit = std::max(1, (per_cu * cus + g.nct - 1) / g.nct);
+  nsplit = std::min(nsplit, std::max(1, g.ntiles / 4));
+  g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
+  nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
+  const int nwg = nsplit * g.nct;
+  const int pq = a.seg[0].q ? 2 : 0;
+  const bool acc = a.accumulate != 0;
+  if (dtype == DT_F16) {
+    if (pq) return acc ? launch_bw1_t<f16, 2, true>(g, nwg, st) : launch_bw1_t<f16, 2, false>(g, nwg, st);
+    return acc ? launch_bw1_t<f16, 0, true>(g, nwg, st) : launch_bw1_t<f16, 0, false>(g, nwg, st);
+  }
+  if (pq) return acc ? launch_bw1_t<bf16, 2, true>(g, nwg, st) : launch_bw1_t<bf16, 2, false>(g, nwg, st);
+  return acc ? launch_bw1_t<bf16, 0, true>(g, nwg, st) : launch_bw1_t<bf16, 0, false>(g, nwg, st);
+}
+
+}  // namespace dmm

@@ -42,6 +42,7 @@ int dmm_set_option(const char* name, int value) {
   if (std::string(name) == "wgp") { dmm::wgp_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "wg5") { dmm::wg5_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "cvp") { dmm::cvp_set_enabled(value != 0); return DMM_OK; }
+  if (std::string(name) == "bw1") { dmm::bw1_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "grad_bucket_mb") {  // applies to plans created afterwards; 0 = one bucket
     if (value < 0) return fail(DMM_ERR_INVALID, "grad_bucket_mb must be >= 0");
     g_bucket_mb = value;
@@ -200,6 +201,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_CONVERT: e = launch_convert_input(o.cv, dt, lst); break;
       case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst); break;
       case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst); break;
+      case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
       case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, lst); break;

@@ -652,7 +652,17 @@ struct Builder {
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
-    conv_grad_done(c);
+    // A dense layer's 1x1 bottleneck convolution: its weight gradient and its data gradient read the same three tensors; when the
+    // pair qualifies (bw1.hip) the weight-gradient launch is taken back here and folded into the data-gradient launch below.
+    bool pending_w = false;
+    Op saved_w;
+    if (d.use_mfma && !c.wgrad_transposed && c.phases.size() == 1 && c.nseg == 1 && c.seg[0].dgrad == DG_FLIP && c.R == 1 && c.S == 1 &&
+        !ops->empty() && ops->back().kind == OP_WGRAD && !leaf_scope) {
+      saved_w = ops->back();
+      ops->pop_back();
+      pending_w = true;
+    }
+    if (!pending_w) conv_grad_done(c);
     // ---- data gradients with fused BN+ReLU backward ----
     for (int s = 0; s < c.nseg; ++s) {
       SegRec& sr = c.seg[s];
@@ -702,8 +712,30 @@ struct Builder {
         tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : "igemm.bnbwd"), pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
+      if (pending_w) {
+        pending_w = false;
+        Op dgrad_op = ops->back();
+        if (!raw && bw1_eligible(saved_w.w, dgrad_op.c, dtype)) {
+          Op& f = ops->back();
+          f.kind = OP_BW1;
+          f.b1.dpack = saved_w.w.dpack;
+          f.b1.dNpad = saved_w.w.Npad;
+          f.b1.wC = saved_w.w.seg[0].C;
+          f.b1.nct = f.b1.ntiles = f.b1.tiles_per_wg = 0;
+          char cb[32];
+          // the pair's traffic with every operand read once: the data gradient's bytes + the packed weight gradient
+          tag(f, ncls("bw1", f.c.Npad, cb), short_name(c.wname), dgrad_op.flops + saved_w.flops, dgrad_op.bytes + w_bytes(c) * 4.0 / esz);
+          conv_grad_done(c);
+        } else {  // not this time: weight gradient, bucket bookkeeping, data gradient - in the original order
+          ops->pop_back();
+          ops->push_back(saved_w);
+          conv_grad_done(c);
+          ops->push_back(dgrad_op);
+        }
+      }
       if (!raw) sb.ginit = true;
     }
+    if (pending_w) { ops->push_back(saved_w); conv_grad_done(c); pending_w = false; }  // (no data gradient was emitted)
     int done = -1;
     for (int s = 0; s < c.nseg; ++s) {
       const int bn = c.seg[s].bn;

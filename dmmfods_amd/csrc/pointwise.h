@@ -141,6 +141,16 @@ struct PackDesc {
   PackSeg seg[2];
 };
 
+// Fused backward of a dense layer's 1x1 bottleneck convolution (bw1.hip): the data-gradient launch `c` (EPI_BNBWD) plus the
+// packed weight gradient of the same convolution.
+struct Bw1Args {
+  ConvArgs c;
+  float* dpack;       // fp32 packed weight gradient [chunk = c / 32][dNpad][32]
+  int dNpad, wC;      // its row pitch (128) and the real number of input channels
+  int nct, ntiles, tiles_per_wg;  // (filled by the launcher)
+};
+bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype);
+hipError_t launch_bw1(const Bw1Args& g, int dtype, hipStream_t st);
 hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st);
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st);
 void thin_set_enabled(bool on);  // thin.hip
@@ -149,6 +159,7 @@ void wg3_set_enabled(bool on);    // wg3.hip
 void wgp_set_enabled(bool on);    // wgp.hip
 void wg5_set_enabled(bool on);    // wg5.hip
 void cvp_set_enabled(bool on);    // cvp.hip
+void bw1_set_enabled(bool on);    // bw1.hip
 bool cvp_handles(const ConvArgs& a, int dtype, int epi);
 bool conv3_handles(const ConvArgs& a, int dtype, int epi);
 bool wg3_handles(const WgradArgs& a, int dtype);
