@@ -23,11 +23,17 @@ namespace dmm {
 constexpr int B1_TM = 64;                       // pixels per tile
 constexpr int B1_NB = 128;                      // bottleneck channels (K of the data gradient, N of the weight gradient)
 constexpr int B1_CT = 128;                      // input channels per workgroup
-constexpr int B1_IMG = B1_TM * 256;             // 16 KB: 64 rows x 256 bytes, 16-byte slot XOR-ed with (row & 15)
+constexpr int B1_IMG = B1_TM * 256;             // 16 KB: 64 rows x 256 bytes, slots permuted per row (b1_swz)
 constexpr int B1_W = 4 * B1_CT * 64;            // 32 KB: the weight slice [chunk][c][32 n], igemm's B image
 constexpr int B1_STAGE = B1_TM * B1_CT * 4;     // fp32 tile over the two operand images
 static_assert(B1_STAGE == 2 * B1_IMG, "staging aliases the operand images exactly");
 constexpr int B1_LDS = 2 * B1_IMG + B1_W + 2 * B1_CT * 8 + 6 * B1_CT * 4;  // + fp64 reduction scratch + per-channel constants
+
+// Physical 16-byte slot of (row, slot) in a 256-byte image row.  The images are read two ways: 16 rows x one slot (ds_read_b128
+// fragments of the data-gradient GEMM) and 4 consecutive rows x 32 contiguous bytes (ds_read_b64_tr_b16 of the weight-gradient
+// GEMM).  The 64-byte granule is XOR-ed with (row & 3), the slot inside it with (row >> 2) & 3: 16 rows hit 16 different slots, 4
+// consecutive rows 4 different granules, and a 32-byte span stays inside its granule.  Rows 16 apart share the permutation.
+__device__ __forceinline__ int b1_swz(int row, int slot) { return ((((slot >> 2) ^ (row & 3)) << 2) | ((slot & 3) ^ ((row >> 2) & 3))); }
 
 typedef unsigned b1_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ b1_u32x2 b1_tr16(const unsigned char* p) {
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int p = p0 + 16 * i;
-    lds[i] = p * 256 + ((cs ^ (p & 15)) << 4);
+    lds[i] = p * 256 + (b1_swz(p, cs) << 4);
   }
 
   // ---- the weight slice, once: chunks of 32 bottleneck channels x 128 input channels (igemm's B image, XOR swizzle) ----
@@ -127,15 +133,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   // ---- fragments ----
   // data gradient: wave w -> pixel rows 32 (w & 1) .., input channels 64 (w >> 1) ..  (2 tiles of 32 columns)
   const int dpx = 32 * (wave & 1) + r;
-  const int dgoff = dpx * 256;            // + ((slot ^ (dpx & 15)) << 4) per k-step
-  const int dkey = dpx & 15;
+  const int dgoff = dpx * 256;            // + (b1_swz(dpx, slot) << 4) per k-step
   const int dcb = 64 * (wave >> 1);       // first column of this wave's half
   const int bsw = (r >> 2) & 3;
   // weight gradient: wave w -> input channels 32 w .. (rows of dP chunk c0 / 32 + w), all 128 bottleneck channels (4 tiles)
   const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
   const int arow = 8 * (tg >> 1) + tq;    // pixel row of the first transposing read; the second is 4 rows further
-  auto tr_off = [&](int px, int colbyte) { return px * 256 + ((((colbyte >> 4) ^ (px & 15)) << 4) | (colbyte & 15)); };
-  // a k-step further down the tile is 16 rows = 4096 bytes further: (row & 15), the swizzle key, does not change
+  auto tr_off = [&](int px, int colbyte) { return px * 256 + ((b1_swz(px, colbyte >> 4) << 4) | (colbyte & 15)); };
+  // a k-step further down the tile is 16 rows = 4096 bytes further: the slot permutation of the row does not change
   const int acolb = (32 * wave + 16 * (tg & 1) + 4 * tp) * 2;
   const int aoff1 = tr_off(arow, acolb), aoff2 = tr_off(arow + 4, acolb);
   int goff1[4], goff2[4];
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   issue(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
     // ---- operands to LDS (prologues once per element); raw x and the old gradient stay in registers for the epilogue ----
-    V xraw[NL], gold[ACC ? NL : 1];  // (the old gradient is requested behind the MFMAs: it lands while the tile is staged)
+    V xraw[NL], gold[ACC ? NL : 1];
     const unsigned ok = okp;
     {
       SlotK<SLOT> kx, kg;
@@ -176,6 +181,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     }
     __syncthreads();  // images (and, the first time, the weight slice) complete
     if (tile + 1 < t_end) issue(tile + 1);
+    if constexpr (ACC) {  // the old gradient of this tile: requested now, needed behind the MFMAs
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const size_t mm = (size_t)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
+        gold[i] = *(const V*)(gout + mm * a.ldo);
+      }
+    }
 
     // ---- data gradient: dX[64 px][128 c] = G W ----
     f32x16 accd[2];
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int slot = ch * 4 + 2 * s + h;
-        const V av = *(const V*)(Gi + dgoff + ((slot ^ dkey) << 4));
+        const V av = *(const V*)(Gi + dgoff + (b1_swz(dpx, slot) << 4));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const V bv = *(const V*)(Wi + ch * (B1_CT * 64) + (dcb + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
@@ -203,13 +215,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
       for (int j = 0; j < 4; ++j) {
         const V gf = b1_frag<T>(b1_tr16(Gi + goff1[j] + ms * 4096), b1_tr16(Gi + goff2[j] + ms * 4096));
         accw[j] = mma16(gf, af, accw[j]);  // rows: bottleneck channel n, columns: input channel c
-      }
-    }
-    if constexpr (ACC) {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const size_t mm = (size_t)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
-        gold[i] = *(const V*)(gout + mm * a.ldo);
       }
     }
     __syncthreads();  // all waves done with the images: stage the data-gradient tile over them
