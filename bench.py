@@ -119,6 +119,8 @@ def measured_traffic(cls, workload):
         # rocprof sees kernel names, not the plan's labels: the generic weight-gradient kernel (normal and transposed form) is one
         # class there ("wgrad*.nN"); it stands for the plan's "wgrad.nN" when the launch counts of the step agree
         e = d.get("classes", {}).get(cls) or d.get("classes", {}).get(cls.replace("wgrad.", "wgrad*."))
+        if e is None and cls.startswith("bw1."):   # one kernel, labelled by the padded input width in the plan: the PMC class is "bw1"
+            e = d.get("classes", {}).get("bw1")
         if e:
             return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
     return None

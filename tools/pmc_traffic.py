@@ -33,6 +33,8 @@ def classify(name):
         return "cvp.store.n128"
     if "cvd_kernel" in name:
         return "cvp.bnbwd.n128"
+    if "bw1_kernel" in name:
+        return "bw1"
     m = re.search(r"halo_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"igemm.{EPI.get(m.group(2), m.group(2))}.n{m.group(1)}"
