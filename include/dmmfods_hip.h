@@ -70,8 +70,9 @@ const char* dmm_last_error(void);
 int dmm_version(void);
 /* Kernel selection switches for tests and A/B timing: "thin_logits" (1 = gather-once kernel for the heat-map head's last
  * convolution, 0 = generic kernels), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the data-gradient
- * chain, 0 = one stream), "conv3" / "wg3" / "wgp" / "wg5" (1 = the LDS halo-tile kernels for the multi-tap convolutions / for the growth
- * convolution's weight gradient / for the weight gradients of the parity-phase convolutions / of the 5x5 head convolution, 0 = generic kernels), "grad_bucket_mb" (size of the data-parallel gradient buckets of plans created afterwards).
+ * chain, 0 = one stream), "conv3" / "wg3" / "wgp" / "wg5" / "cvp" / "bw1" (1 = the LDS halo-tile kernels for the multi-tap convolutions / for the growth
+ * convolution's weight gradient / for the weight gradients of the parity-phase convolutions / of the 5x5 head convolution / the ConvTranspose kernels / the fused backward of the 1x1 bottleneck convolutions, decided when a
+ * plan is created; 0 = generic kernels), "grad_bucket_mb" (size of the data-parallel gradient buckets of plans created afterwards).
  * Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32 summation
  * order. */
 int dmm_set_option(const char* name, int value);
