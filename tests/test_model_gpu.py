@@ -478,12 +478,12 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-def test_fused_bottleneck_backward_matches_separate_kernels(dtype):
-    """bw1.hip (data gradient + weight gradient of every dense layer's 1x1 bottleneck convolution in one pass) against the two
-    generic kernels inside DenseNet-121, on maps whose pixel counts are not multiples of the 64-row tile and input widths that are
-    not multiples of the 128-channel slice (64 ... 1024 channels).  The weight gradients see bit-identical operands (only the fp32
-    summation order differs); the data gradients differ by the 16-bit rounding of the running block gradient, which is
-    stored between layers on either path."""
+@pytest.mark.parametrize("opt", ["bw1"])
+def test_fused_dense_layer_backward_matches_separate_kernels(opt, dtype):
+    """bw1.hip (data gradient + weight gradient of every dense layer's 1x1 bottleneck convolution in one pass; the same fusion for
+    the 3x3 growth convolution was built, verified with this test and dropped: see DESIGN.md) against the separate kernels inside DenseNet-121, on maps whose pixel counts are not multiples of the tiles and input
+    widths that are not multiples of the 128-channel slice (64 ... 1024 channels).  The weight gradients see (nearly) identical
+    operands; the data gradients differ by the 16-bit rounding of gradients that are stored between layers on either path."""
     import ctypes as C
     from oracle import restatement as R
     from dmmfods_amd import _lib
@@ -497,7 +497,7 @@ def test_fused_bottleneck_backward_matches_separate_kernels(dtype):
     out = {}
     try:
         for on in (1, 0):
-            _lib.check(L.dmm_set_option(b"bw1", on))
+            _lib.check(L.dmm_set_option(opt.encode(), on))
             model._plans.clear()                     # the fusion is decided when the plan is built
             with torch.no_grad():
                 model(rgb, lidar)
@@ -510,20 +510,20 @@ def test_fused_bottleneck_backward_matches_separate_kernels(dtype):
                 L.dmm_plan_profile_op(plan.handle, 1, i, C.byref(label), C.byref(fl), C.byref(by))
                 labels.append((label.value or b"").decode())
             out[on] = (met["loss_per_class"].clone(), {k: p.grad.detach().double().clone() for k, p in model.named_parameters()},
-                       sum(1 for x in labels if x.startswith("bw1.")))
+                       sum(1 for x in labels if x.startswith(opt + ".")))
             model._tracked_arena.zero_()
     finally:
-        _lib.check(L.dmm_set_option(b"bw1", 1))
+        _lib.check(L.dmm_set_option(opt.encode(), 1))
         model._plans.clear()
     assert out[1][2] >= 58 and out[0][2] == 0, (out[1][2], out[0][2])      # every dense layer of DenseNet-121 (+ a 128-wide decoder 1x1)
     assert _rel(out[1][0], out[0][0]) < 1e-6                                # the forward pass is untouched
     g1, g0 = out[1][1], out[0][1]
-    last = "features.denseblock4.denselayer16.conv1.weight"                 # only the decoder's fused 1x1 runs upstream of this one
+    last = "features.denseblock4.denselayer16.conv%d.weight" % (1 if opt == "bw1" else 2)   # little or nothing fused runs upstream
     e_last = ((g1[last] - g0[last]).norm() / g0[last].norm()).item()
     num = sum(float((g1[k] - g0[k]).pow(2).sum()) for k in g1)
     den = sum(float(g0[k].pow(2).sum()) for k in g1)
     e_all = (num / den) ** 0.5
-    print(f"bw1 vs separate kernels ({dtype}): last bottleneck weight gradient rel L2 {e_last:.3e}; all gradients rel L2 {e_all:.3e}")
+    print(f"{opt} vs separate kernels ({dtype}): last layer's weight gradient rel L2 {e_last:.3e}; all gradients rel L2 {e_all:.3e}")
     assert all(torch.isfinite(v).all() for v in g1.values())
-    assert e_last < (3e-3 if dtype == "fp16" else 3e-2)       # measured 6.4e-4 (fp16)
-    assert e_all < (2e-2 if dtype == "fp16" else 1e-1)        # measured 6.6e-4 (fp16)
+    assert e_last < (3e-3 if dtype == "fp16" else 3e-2)       # bw1 measured 6.4e-4 (fp16) / 4.6e-3 (bf16)
+    assert e_all < (2e-2 if dtype == "fp16" else 1e-1)        # bw1 measured 6.6e-4 (fp16) / 5.1e-3 (bf16)
