@@ -45,6 +45,9 @@ constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
 #ifndef IGEMM_FAT
 #define IGEMM_FAT 0  // instantiate the 8-wave variants (measured: no gain)
 #endif
+#ifndef IGEMM_ACCSTAT
+#define IGEMM_ACCSTAT 1  // EPI_STORE statistics from the accumulator layout
+#endif
 #ifndef IGEMM_EPI_EARLY
 #define IGEMM_EPI_EARLY 0
 #endif
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
   typedef IgemmSmem<T, BN, KSV> SM;
   constexpr int NT = BN / 32;
   constexpr int KS = KSV;
+  constexpr bool ACCSTAT = IGEMM_ACCSTAT && MFMA && NW == 4 && sizeof(T) == 2;  // (fp32 storage keeps the row-wise form: its parity tests pin it)
   constexpr int NB = KS * BN / (16 * NW);  // 1-KiB LDS-DMA pieces of the B image per wave per stage
   constexpr int RST = NTHREADS / KS / 4;   // row groups; a thread owns rows rg + RST i
   constexpr int NR = BM / RST;             // rows per thread
@@ -438,13 +442,28 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
   if (wave < 4) {
     if (EPI == EPI_STORE) {
       T* Cs = (T*)smem;
+      // BatchNorm statistics straight from the accumulator layout (as conv3.hip / cvp.hip): lane (r, h) holds column 32 t + r of 16
+      // rows; column sums of the values AS STORED (rounded to T), the two lane halves folded, one LDS word per column and wave
+      float* wpart = (float*)red;  // [wave][2][BN] floats over the fp64 scratch + row table (both dead here; NW == 4 only)
+      bool rok[16];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int i = 0; i < 16; ++i) rok[i] = rowpix[32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h] >= 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float ps1 = 0.f, ps2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-          Cs[row * SM::STAGE_PITCH_T + 32 * t + r] = from_f32<T>(acc[t][i]);
+          const T v = from_f32<T>(acc[t][i]);
+          Cs[row * SM::STAGE_PITCH_T + 32 * t + r] = v;
+          if (ACCSTAT && rok[i]) { const float f = to_f32(v); ps1 += f; ps2 = fmaf(f, f, ps2); }
         }
+        if (ACCSTAT) {
+          ps1 += __shfl_xor(ps1, 32, 64);
+          ps2 += __shfl_xor(ps2, 32, 64);
+          if (h == 0) { wpart[(wave * 2 + 0) * BN + 32 * t + r] = ps1; wpart[(wave * 2 + 1) * BN + 32 * t + r] = ps2; }
+        }
+      }
     } else {
       float* Cs = (float*)smem;
 #pragma unroll
@@ -485,12 +504,28 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
       if (pix < 0 || !colvalid) continue;
       const V v = *(const V*)(Cs + row * SM::STAGE_PITCH_T + cv * SLOT);
       *(V*)(out + (size_t)pix * a.ldo + n) = v;
-      float f[SLOT];
-      vec_to_f32<T>(v, f);
+      if (!ACCSTAT) {
+        float f[SLOT];
+        vec_to_f32<T>(v, f);
 #pragma unroll
-      for (int i = 0; i < SLOT; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
+        for (int i = 0; i < SLOT; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
+      }
     }
     if (a.stat_sum == nullptr) return;
+    if (ACCSTAT) {  // four wave partials per column -> fp64 -> one atomic per column and workgroup (per-XCD replica)
+      const float* wpart = (const float*)red;
+      if (!(IGEMM_DBG & 32) && tid < 2 * BN) {
+        const int col = tid % BN, which = tid / BN;
+        if (n0 + col < a.N) {
+          double s = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) s += (double)wpart[(w * 2 + which) * BN + col];
+          const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+          atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + n0 + col, s);
+        }
+      }
+      return;
+    }
   } else {  // EPI_BNBWD
     const float* Cs = (const float*)smem;
     const T* bx = (const T*)a.bx;
