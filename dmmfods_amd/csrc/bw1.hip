@@ -68,7 +68,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int ct = blockIdx.x % g.nct, split = blockIdx.x / g.nct;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The nct workgroups that walk the same rows
+  // (one per 128-channel slice) all read the same G and y tiles: they get consecutive slots of ONE XCD, so the tiles come from HBM once.
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ct = q % g.nct, split = (q / g.nct) * 8 + xcd;
   const int c0 = ct * B1_CT;
   const int t_beg = split * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
   if (t_beg >= t_end) return;
@@ -341,7 +344,7 @@ hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
   nsplit = std::min(nsplit, std::max(1, g.ntiles / 4));
   g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
   nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
-  const int nwg = nsplit * g.nct;
+  const int nwg = ((nsplit + 7) / 8) * 8 * g.nct;  // whole groups of 8 row ranges (one per XCD); surplus workgroups return at once
   const int pq = a.seg[0].q ? 2 : 0;
   const bool acc = a.accumulate != 0;
   if (dtype == DT_F16) {
