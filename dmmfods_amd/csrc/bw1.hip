@@ -70,8 +70,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   const int r = lane & 31, h = lane >> 5;
   // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The nct workgroups that walk the same rows
   // (one per 128-channel slice) all read the same G and y tiles: they get consecutive slots of ONE XCD, so the tiles come from HBM once.
+  // (Launches with few row ranges keep the plain order: rounding them up to groups of 8 costs more than the re-reads.)
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int ct = q % g.nct, split = (q / g.nct) * 8 + xcd;
+  const int ct = g.xcd_group ? q % g.nct : (int)(blockIdx.x % g.nct);
+  const int split = g.xcd_group ? (q / g.nct) * 8 + xcd : (int)(blockIdx.x / g.nct);
   const int c0 = ct * B1_CT;
   const int t_beg = split * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
   if (t_beg >= t_end) return;
@@ -344,7 +346,8 @@ hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
   nsplit = std::min(nsplit, std::max(1, g.ntiles / 4));
   g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
   nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
-  const int nwg = ((nsplit + 7) / 8) * 8 * g.nct;  // whole groups of 8 row ranges (one per XCD); surplus workgroups return at once
+  g.xcd_group = (g.nct > 1 && nsplit >= 32 && g.tiles_per_wg >= 8) ? 1 : 0;  // (measured: block 1-2 gain, block 3 loses)
+  const int nwg = g.xcd_group ? ((nsplit + 7) / 8) * 8 * g.nct : nsplit * g.nct;  // whole groups of 8 row ranges (one per XCD); surplus workgroups return at once
   const int pq = a.seg[0].q ? 2 : 0;
   const bool acc = a.accumulate != 0;
   if (dtype == DT_F16) {

@@ -721,7 +721,7 @@ struct Builder {
           f.b1.dpack = saved_w.w.dpack;
           f.b1.dNpad = saved_w.w.Npad;
           f.b1.wC = saved_w.w.seg[0].C;
-          f.b1.nct = f.b1.ntiles = f.b1.tiles_per_wg = 0;
+          f.b1.nct = f.b1.ntiles = f.b1.tiles_per_wg = f.b1.xcd_group = 0;
           char cb[32];
           // the pair's traffic with every operand read once: the data gradient's bytes + the packed weight gradient
           tag(f, ncls("bw1", f.c.Npad, cb), short_name(c.wname), dgrad_op.flops + saved_w.flops, dgrad_op.bytes + w_bytes(c) * 4.0 / esz);

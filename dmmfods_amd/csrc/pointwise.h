@@ -147,7 +147,7 @@ struct Bw1Args {
   ConvArgs c;
   float* dpack;       // fp32 packed weight gradient [chunk = c / 32][dNpad][32]
   int dNpad, wC;      // its row pitch (128) and the real number of input channels
-  int nct, ntiles, tiles_per_wg;  // (filled by the launcher)
+  int nct, ntiles, tiles_per_wg, xcd_group;  // (filled by the launcher)
 };
 bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype);
 hipError_t launch_bw1(const Bw1Args& g, int dtype, hipStream_t st);
