@@ -270,30 +270,38 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
       float g[SLOT];
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) g[i] = 0.f;
-      // windows (oy, ox) with 2*oy-1 <= y <= 2*oy+1
+      // windows (oy, ox) with 2*oy-1 <= y <= 2*oy+1: up to two per axis.  All four candidates are loaded before the first use
+      // (clamped to a valid window, dropped by the predicate): one memory latency per pixel instead of one per window.
       const int oy0 = y >> 1, oy1 = (y + 1) >> 1;  // oy0 <= oy1, may coincide
       const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
-      for (int wy = oy0; wy <= oy1; ++wy) {
-        if (wy >= a.Hp) continue;
-        const int ky = y - (2 * wy - 1);
-        for (int wx = ox0; wx <= ox1; ++wx) {
-          if (wx >= a.Wp) continue;
-          const int kx = x - (2 * wx - 1);
-          const int k = ky * 3 + kx;
-          const size_t op = (size_t)(b * a.Hp + wy) * a.Wp + wx;
-          float gf[SLOT], xf[SLOT];
-          vec_to_f32<T>(*(const V*)(gp + op * a.ldg + c), gf);
-          vec_to_f32<T>(*(const V*)(xp + op * a.ldg + c), xf);
-          unsigned long long am;  // the slot's argmax bytes in one load
-          if constexpr (SLOT == 8) am = *(const unsigned long long*)(a.argmax + op * a.C + c);
-          else am = *(const unsigned*)(a.argmax + op * a.C + c);
+      V wg[4], wx_[4];
+      unsigned long long wam[4];
+      bool wok[4];
+      int wk[4];
 #pragma unroll
-          for (int i = 0; i < SLOT; ++i)
-            if ((int)((am >> (8 * i)) & 0xff) == k) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
-        }
+      for (int w = 0; w < 4; ++w) {
+        const int wy = (w >> 1) ? oy1 : oy0, wx = (w & 1) ? ox1 : ox0;
+        wok[w] = ((w >> 1) == 0 || oy1 != oy0) && ((w & 1) == 0 || ox1 != ox0) && wy < a.Hp && wx < a.Wp;
+        const int cy = min(wy, a.Hp - 1), cx = min(wx, a.Wp - 1);
+        wk[w] = (y - (2 * wy - 1)) * 3 + (x - (2 * wx - 1));
+        const size_t op = (size_t)(b * a.Hp + cy) * a.Wp + cx;
+        wg[w] = *(const V*)(gp + op * a.ldg + c);
+        wx_[w] = *(const V*)(xp + op * a.ldg + c);
+        if constexpr (SLOT == 8) wam[w] = *(const unsigned long long*)(a.argmax + op * a.C + c);
+        else wam[w] = *(const unsigned*)(a.argmax + op * a.C + c);
+      }
+      const V y0v = *(const V*)(y0 + (size_t)p * a.ld0 + c);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float gf[SLOT], xf[SLOT];
+        vec_to_f32<T>(wg[w], gf);
+        vec_to_f32<T>(wx_[w], xf);
+#pragma unroll
+        for (int i = 0; i < SLOT; ++i)
+          if (wok[w] && (int)((wam[w] >> (8 * i)) & 0xff) == wk[w]) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
       }
       float yf[SLOT], o[SLOT];
-      vec_to_f32<T>(*(const V*)(y0 + (size_t)p * a.ld0 + c), yf);
+      vec_to_f32<T>(y0v, yf);
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
         const float dz = (fmaf(yf[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
