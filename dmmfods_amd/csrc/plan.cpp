@@ -648,7 +648,7 @@ struct Builder {
         char cb[32];
         const double np = (double)c.phases.size();
         // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
-        tag(o, ncls((d.use_mfma && wgp_handles(a, dtype)) ? "wgp" : "wgrad", pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        tag(o, ncls((d.use_mfma && wgp_handles(a, dtype)) ? "wgp" : ((d.use_mfma && wg5_handles(a, dtype)) ? "wg5" : "wgrad"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }

@@ -18,12 +18,21 @@
 
 namespace dmm {
 
-constexpr int W5_TH = 8, W5_TW = 16, W5_HH = 12, W5_HW = 20;  // tile, halo (taps span -2..2)
+constexpr int W5_TH = 8, W5_TW = 16;
 constexpr int W5_CA = 64;
-constexpr int W5_NCH = 7;                                     // 25 taps x 8 columns = 200 -> seven 32-column chunks
 constexpr int W5_A_BYTES = BM * W5_CA * 2;                    // 16 KB, 128-byte rows, 64-byte granule XOR-ed with (row >> 1) & 1
-constexpr int W5_Y_BYTES = W5_HH * W5_HW * 16 + 64;           // halo image + a zero line for the 3 columns groups past tap 24
-constexpr int W5_LDS = W5_A_BYTES + W5_Y_BYTES;
+// TR = tap radius, STR = source stride of the thin operand: (5x5, stride 1) = the head's last convolution; (7x7, stride 2) = the
+// stem convolution conv0 (reference M:47-52 / torchvision features.conv0), whose thin operand is the raw input.
+template <int TR, int STR>
+struct W5Geo {
+  static constexpr int NT = (2 * TR + 1) * (2 * TR + 1);        // taps
+  static constexpr int NCH = (NT * 8 + 31) / 32;                // 32-column chunks of the (tap, thin channel) columns: 7 / 13
+  static constexpr int NQ = (NCH + 1) / 2;                      // chunks per wave pair
+  static constexpr int HH = STR * (W5_TH - 1) + 2 * TR + 1, HW = STR * (W5_TW - 1) + 2 * TR + 1;  // halo: 12 x 20 / 21 x 37
+  static constexpr int Y_BYTES = HH * HW * 16 + 64;             // halo image + a zero line for the column groups past the last tap
+  static constexpr int LDS = W5_A_BYTES + Y_BYTES;
+  static constexpr int NYL = (HH * HW + NTHREADS - 1) / NTHREADS;  // halo pixels per thread
+};
 
 struct Wg5Args {
   WgradArgs w;
@@ -43,10 +52,13 @@ __device__ __forceinline__ typename TT<T>::vec w5_frag(const w5_u32x2& lo, const
   return __builtin_bit_cast(typename TT<T>::vec, v);
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
+// PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient)
+template <typename T, int TR, int STR, int PA>
+__global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
+  typedef W5Geo<TR, STR> G5;
+  constexpr int W5_HH = G5::HH, W5_HW = G5::HW, W5_NCH = G5::NCH, NYL = G5::NYL;
   constexpr int SLOT = 8;
   constexpr int NA = BM * (W5_CA / SLOT) / NTHREADS;  // 4 A slots per thread
   const WgradArgs& a = g.w;
@@ -65,10 +77,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
   // ---- fixed channel positions: prologue constants once ----
   const int ca = tid & 7, pa0 = tid >> 3;  // A: slot column, pixels pa0 + 32 i
   SlotK<SLOT> ka;
-  ka.k0 = load_fv<SLOT>(sa.scale + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.shift + ca * SLOT); ka.k2 = 0.f; ka.k3 = 0.f;
+  ka.k0 = 0.f; ka.k1 = 0.f; ka.k2 = 0.f; ka.k3 = 0.f;
+  if (PA == 1) { ka.k0 = load_fv<SLOT>(sa.scale + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.shift + ca * SLOT); }
+  if (PA == 2) { ka.k0 = load_fv<SLOT>(sa.q + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.r + ca * SLOT); }
   const T* asrc = (const T*)sa.src + ca * SLOT;
+  const T* asrc2 = (const T*)sa.src2 + ca * SLOT;
   const T* ysrc = (const T*)sy.src;
-  const int hy_ = tid / W5_HW, hx_ = tid - hy_ * W5_HW;  // dY: halo pixel `tid` (threads 0..239)
   int alds[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -76,14 +90,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
     alds[i] = p * 128 + ((ca * 16) ^ (((p >> 1) & 1) << 6));
   }
   if (tid < 4) *(V*)(Ys + ZERO + tid * 16) = V{};  // the zero line (never rewritten)
+  (void)NA;
 
   // Two register sets: the loads of tile t + 2 are issued while tile t is contracted (a tile's contraction is short next to a
   // memory latency).  Every load is issued unconditionally (clamped tile / pixel), so the number of loads behind a given one is a
   // compile-time constant and the compiler's counted s_waitcnt in store() leaves the other set in flight.
   struct Regs {
-    V ra[NA], ry;
-    unsigned oka;
-    bool oky;
+    V ra[NA], ra2[PA == 2 ? NA : 1], ry[NYL];
+    unsigned oka, oky;
   };
   Regs R0, R1;
   const int tiles_img = g.tiles_y * g.tiles_x;
@@ -99,11 +113,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
       if (y < a.Ho && x < a.Wo) R.oka |= 1u << i;
       const size_t pix = (size_t)(b * sa.Hs + min(y, sa.Hs - 1)) * sa.Ws + min(x, sa.Ws - 1);
       R.ra[i] = *(const V*)(asrc + pix * sa.ld);
+      if constexpr (PA == 2) R.ra2[i] = *(const V*)(asrc2 + pix * sa.ld2);
     }
-    const int y = y0 - 2 + hy_, x = x0 - 2 + hx_;
-    R.oky = tid < W5_HH * W5_HW && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws;
-    const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
-    R.ry = *(const V*)(ysrc + pix * sy.ld);
+    R.oky = 0;
+#pragma unroll
+    for (int i = 0; i < NYL; ++i) {
+      const int hp = tid + NTHREADS * i;
+      const int hy = hp / W5_HW, hx = hp - hy * W5_HW;
+      const int y = y0 * STR - TR + hy, x = x0 * STR - TR + hx;
+      if (hp < W5_HH * W5_HW && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws) R.oky |= 1u << i;
+      const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
+      R.ry[i] = *(const V*)(ysrc + pix * sy.ld);
+    }
   };
   auto store = [&](const Regs& R) {
     V z;
@@ -111,14 +132,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
     for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const V v = bn_relu_slot(R.ra[i], ka);
+      V v = R.ra[i];
+      if constexpr (PA == 1) v = bn_relu_slot(R.ra[i], ka);
+      if constexpr (PA == 2) v = eff_grad_slot(R.ra[i], R.ra2[i], ka);
       *(V*)(As + alds[i]) = ((R.oka >> i) & 1) ? v : z;
     }
-    if (tid < W5_HH * W5_HW) *(V*)(Ys + tid * 16) = R.oky ? R.ry : z;
+#pragma unroll
+    for (int i = 0; i < NYL; ++i) {
+      const int hp = tid + NTHREADS * i;
+      if (hp < W5_HH * W5_HW) *(V*)(Ys + hp * 16) = ((R.oky >> i) & 1) ? R.ry[i] : z;
+    }
   };
 
-  // wave w: input channels 32 (w & 1) .., chunks (w >> 1), (w >> 1) + 2, ...  (4 chunks for waves 0-1, 3 for waves 2-3)
-  constexpr int NQ = 4;
+  // wave w: 64-channel operand rows 32 (w & 1) .., chunks (w >> 1), (w >> 1) + 2, ...
+  constexpr int NQ = G5::NQ;
   const int cw = wave & 1, q0 = wave >> 1;
   f32x16 acc[NQ];
 #pragma unroll
@@ -139,9 +166,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wg5_kernel(const Wg5Args g) {
     const bool live = q < W5_NCH && tap < sy.ntaps;
     const int tw = sy.taps[live ? tap : 0];
     const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
-    boff[m] = live ? ((2 + dy) * W5_HW + arow + 2 + dx) * 16 + (tp & 1) * 8 : ZERO + (tp & 1) * 8;
-    bstep[m] = live ? W5_HW * 16 : 0;  // one tile row further in the halo image
-    bsec[m] = live ? 4 * 16 : 0;       // the fragment's second half: 4 pixels further
+    boff[m] = live ? ((TR + dy) * W5_HW + STR * arow + TR + dx) * 16 + (tp & 1) * 8 : ZERO + (tp & 1) * 8;
+    bstep[m] = live ? STR * W5_HW * 16 : 0;  // one tile row further in the halo image
+    bsec[m] = live ? STR * 4 * 16 : 0;       // the fragment's second half: 4 pixels further
   }
 
   auto contract = [&]() {
@@ -194,30 +221,37 @@ void wg5_set_enabled(bool on) { g_wg5 = on; }
 
 static thread_local bool g_wg5_dry = false;
 
-template <typename T>
+template <typename T, int TR, int STR, int PA>
 static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
-  hipLaunchKernelGGL(wg5_kernel<T>, dim3(nwg), dim3(NTHREADS), W5_LDS, st, g);
+  auto kern = wg5_kernel<T, TR, STR, PA>;
+  constexpr int lds = W5Geo<TR, STR>::LDS;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), lds, st, g);
   return hipGetLastError();
 }
 
-// Returns hipErrorNotSupported unless this is the transposed-form weight gradient of a 5x5 convolution from 64 channels to one
-// 8-channel slot in a 16-bit storage type.
+// Takes a weight gradient whose tapped operand (seg[0]) is ONE 8-channel slot and whose pixel-aligned operand (dy) has 64 channels,
+// 16-bit storage:  (a) 25 taps at stride 1, the 64 channels an activation (BN+ReLU): the head's 5x5 convolution, transposed form;
+// (b) 49 taps at stride 2 over the raw input, the 64 channels an output gradient (plain or with the deferred correction): the
+// stem's 7x7 convolution, normal form.  Returns hipErrorNotSupported otherwise.
 hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   if (!g_wg5 || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
   const Seg& q = a.seg[0];
   const Seg& p = a.dy;
-  if (q.mode != G_PLAIN || q.istride != 1 || q.ntaps != 25 || q.C != 8 || q.Cpad != 8 || q.Hs != a.Ho || q.Ws != a.Wo || q.scale != nullptr || q.q != nullptr)
+  const bool stem = q.ntaps == 49;
+  const int tr = stem ? 3 : 2, str = stem ? 2 : 1;
+  if (q.mode != G_PLAIN || q.istride != str || (q.ntaps != 25 && q.ntaps != 49) || q.C != 8 || q.Cpad != 8 || q.Hs != str * a.Ho || q.Ws != str * a.Wo ||
+      q.scale != nullptr || q.q != nullptr)
     return hipErrorNotSupported;
-  if (q.nchunks != W5_NCH) return hipErrorNotSupported;
-  if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo || p.scale == nullptr)
-    return hipErrorNotSupported;
+  if (q.nchunks != (q.ntaps * 8 + 31) / 32) return hipErrorNotSupported;
+  if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo) return hipErrorNotSupported;
+  if (stem ? p.scale != nullptr : (p.scale == nullptr || p.q != nullptr)) return hipErrorNotSupported;
   if (a.N != W5_CA || a.Npad != W5_CA) return hipErrorNotSupported;
-  bool seen[25];
-  for (int t = 0; t < 25; ++t) seen[t] = false;
-  for (int t = 0; t < 25; ++t) {
+  bool seen[49];
+  for (int t = 0; t < 49; ++t) seen[t] = false;
+  for (int t = 0; t < q.ntaps; ++t) {
     const int dy = (int)(signed char)(q.taps[t] & 0xff), dx = (int)(signed char)((q.taps[t] >> 8) & 0xff);
-    if (dy < -2 || dy > 2 || dx < -2 || dx > 2 || seen[(dy + 2) * 5 + dx + 2]) return hipErrorNotSupported;
-    seen[(dy + 2) * 5 + dx + 2] = true;
+    if (dy < -tr || dy > tr || dx < -tr || dx > tr || seen[(dy + tr) * (2 * tr + 1) + dx + tr]) return hipErrorNotSupported;
+    seen[(dy + tr) * (2 * tr + 1) + dx + tr] = true;
   }
   if (g_wg5_dry) return hipSuccess;
   Wg5Args g;
@@ -228,11 +262,14 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   static const int per_cu = getenv("DMM_WG5_PER_CU") ? atoi(getenv("DMM_WG5_PER_CU")) : 2;
-  // every workgroup ends with 57 KB of atomics; a tile costs ~1 us: two workgroups per CU unless the picture is small
-  int nwg = std::max(1, std::min(per_cu * cus, g.ntiles / 8));
+  // every workgroup ends with 57 (stem: 106) KB of atomics; a tile costs ~1 us: two workgroups per CU unless the picture is small
+  int nwg = std::max(1, std::min((stem ? 1 : per_cu) * cus, g.ntiles / 8));  // (the stem form holds one workgroup per CU)
   g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;
   nwg = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
-  return dtype == DT_F16 ? launch_wg5_t<f16>(g, nwg, st) : launch_wg5_t<bf16>(g, nwg, st);
+  const bool f16t = dtype == DT_F16;
+  if (!stem) return f16t ? launch_wg5_t<f16, 2, 1, 1>(g, nwg, st) : launch_wg5_t<bf16, 2, 1, 1>(g, nwg, st);
+  if (p.q) return f16t ? launch_wg5_t<f16, 3, 2, 2>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 2>(g, nwg, st);
+  return f16t ? launch_wg5_t<f16, 3, 2, 0>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 0>(g, nwg, st);
 }
 
 bool wg5_handles(const WgradArgs& a, int dtype) {

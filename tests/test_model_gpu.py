@@ -458,7 +458,9 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     worst = max(((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm()).item() for k in grads[1])
     print(f"wgp vs generic on identical operands ({dtype}): worst rel L2 {worst:.3e}; launches on wgp: {len(on_wgp)}")
     assert all(torch.isfinite(v).all() for v in grads[1].values()) and worst < 2e-4
-    # the same for the head's 5x5 convolution onto the classes (wg5.hip vs the generic transposed form)
+    # the same for the two convolutions with an 8-channel operand (wg5.hip vs the generic kernel): the head's 5x5 onto the classes
+    # (transposed form) and the stem's 7x7 stride 2 over the raw input (normal form, deferred-correction prologue on the gradient)
+    names = ["dec_out_to_heat_maps.refine1.weight", "features.conv0.weight"]
     g5 = {}
     try:
         for on in (1, 0):
@@ -467,13 +469,14 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
                 model(rgb, lidar)
             model.loss_backward(tgt)
             torch.cuda.synchronize()
-            g5[on] = model.dec_out_to_heat_maps.refine1.weight.grad.detach().double().clone()
+            g5[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if k in names}
     finally:
         _lib.check(L.dmm_set_option(b"wg5", 1))
-    assert sum(1 for x in labels if x.startswith("wg5.")) == 1, [x for x in labels if "refine1" in x]
-    e5 = ((g5[1] - g5[0]).norm() / g5[0].norm()).item()
-    print(f"wg5 vs generic on identical operands ({dtype}): rel L2 {e5:.3e}, max |g| {g5[0].abs().max().item():.3e}")
-    assert torch.isfinite(g5[1]).all() and g5[0].abs().max() > 0 and e5 < 2e-4
+    assert sorted(x.split("/")[1] for x in labels if x.startswith("wg5.")) == ["f.conv0", "h.refine1"], [x for x in labels if x.startswith("wg5.")]
+    for k in names:
+        e5 = ((g5[1][k] - g5[0][k]).norm() / g5[0][k].norm()).item()
+        print(f"wg5 vs generic on identical operands ({dtype}) {k}: rel L2 {e5:.3e}, max |g| {g5[0][k].abs().max().item():.3e}")
+        assert torch.isfinite(g5[1][k]).all() and g5[0][k].abs().max() > 0 and e5 < 2e-4
 
 
 @pytest.mark.gpu
