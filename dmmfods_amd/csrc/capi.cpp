@@ -202,6 +202,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst); break;
       case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst); break;
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
+      case OP_JOIN: join(); break;  // the main stream waits for what the side stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
       case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, lst); break;

@@ -1035,13 +1035,26 @@ struct Builder {
   }
 
   void emit_pack_op(int kind) {
+    if (pack_split > 0) {  // the first convolution's weights, on the launch stream
+      Op& o = push(kind);
+      o.pk.descs = pack_dev;
+      o.pk.prefix = prefix_dev;
+      o.pk.ndesc = pack_split;
+      o.pk.total_rows = pack_rows0;
+      o.pk.grad_scale = 1.0f / d.loss_scale;
+      tag(o, "pack", "stem", 0, 0);
+    }
     Op& o = push(kind);
-    o.pk.descs = pack_dev;
-    o.pk.prefix = prefix_dev;
-    o.pk.ndesc = (int)P.packs.size();
+    if (pack_split > 0) o.leaf = 1;  // side stream; OP_JOIN in front of the second convolution (emit_pack_join)
+    o.pk.descs = pack_dev + pack_split;
+    o.pk.prefix = prefix_dev + pack_split;
+    o.pk.ndesc = (int)P.packs.size() - pack_split;
     o.pk.total_rows = total_rows;
     o.pk.grad_scale = 1.0f / d.loss_scale;
     tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
+  }
+  void emit_pack_join() {
+    if (pack_split > 0) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
   }
 
   // ---------------------------------------------------------------- gradient buckets (data-parallel overlap)
@@ -1142,13 +1155,27 @@ struct Builder {
   bool pad_pitch = getenv("DMM_PITCH_PAD") != nullptr;  // measured: no effect on MI355X for this access pattern; off
   PackDesc* pack_dev = nullptr;
   int* prefix_dev = nullptr;
-  int total_rows = 0;
+  int total_rows = 0;          // rows of the pack launch behind the split (all rows without a split)
+  int pack_split = 0, pack_rows0 = 0;
 
   void emit_all() {
     // pack tables live in the workspace
+    // The weights are packed by two launches: the first convolution's (needed at once) on the launch stream, everything else on
+    // the side stream beside the input conversion and the stem convolution (pack_split descriptors / pack_rows0 rows in front;
+    // the row prefix restarts at 0 behind the split).
+    pack_split = 0;
+    if (!recs.empty() && recs[0].type == 0 && getenv("DMM_NO_PACK_SPLIT") == nullptr) {
+      const ConvRec& c0 = convs[recs[0].idx];
+      for (auto& ph : c0.phases) pack_split = std::max(pack_split, ph.pack + 1);
+      for (int s = 0; s < c0.nseg; ++s) if (c0.seg[s].dgrad != DG_NONE) pack_split = std::max(pack_split, c0.dpack[s] + 1);
+      if (pack_split >= (int)P.packs.size()) pack_split = 0;
+    }
     P.pack_prefix.clear();
     total_rows = 0;
-    for (auto& pd : P.packs) {
+    pack_rows0 = 0;
+    for (size_t i = 0; i < P.packs.size(); ++i) {
+      const PackDesc& pd = P.packs[i];
+      if ((int)i == pack_split && pack_split > 0) { pack_rows0 = total_rows; total_rows = 0; }
       P.pack_prefix.push_back(total_rows);
       int chunks = 0;
       for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
@@ -1169,7 +1196,11 @@ struct Builder {
     emit_pack_op(OP_PACK);
     P.convert_ops_train.clear();
     emit_convert(P.convert_ops_train);
-    for (auto& r : recs) { if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]); }
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+      const Rec& r = recs[ri];
+      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
+      if (ri == 0) emit_pack_join();
+    }
     // ---- eval forward ----
     ops = sizing ? &dummy : &P.fwd_eval;
     ops->clear();
@@ -1177,7 +1208,11 @@ struct Builder {
     emit_pack_op(OP_PACK);
     P.convert_ops_eval.clear();
     emit_convert(P.convert_ops_eval);
-    for (auto& r : recs) { if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]); }
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+      const Rec& r = recs[ri];
+      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
+      if (ri == 0) emit_pack_join();
+    }
     // ---- loss + backward ----
     ops = sizing ? &dummy : &P.bwd;
     ops->clear();
