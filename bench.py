@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-throughput benchmark of the Dense_U_Net_lidar hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -198,17 +198,136 @@ def cpu_baseline(min_seconds=10.0, max_steps=60):
         times.append(time.time() - t0)
     best = min(times)
     median = sorted(times)[len(times) // 2]
-    return dict(value=round(1.0 / best, 4), unit="img/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(1.0 / best, 4), unit="img/s", cores=torch.get_num_threads(), cpu_model=cpu_model(), kind="port",
                 sample=f"C1 d121 no-fusion 1x3x256x384 fp32 fwd+BCE+bwd+Adam, {len(times)} steps ({sum(times):.1f} s) after 1 warm-up, best {best:.3f} / median {median:.3f} s/step "
                        f"(= {109.8 / best:.1f} conv GFLOP/s); the GPU workload is 25.4x more conv FLOPs per image")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves, as a child
+    `python -m torch.distributed.run`, BEFORE this process touches the GPU, and pass its exit code on."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no RANK in the environment: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def conv0_dgrad_gflop(c):
+    """a training step is 3x the forward conv FLOPs minus the data gradient of the stem convolution(s), which is never
+    needed (2 * 64 * Cin * 49 * H/2 * W/2 per image and stem)."""
+    stems = [(3 + c["s2"]) if c["cbb"] == 1 else 3] + ([c["s2"]] if c["cbb"] > 1 else [])
+    return sum(2.0 * 64 * cin * 49 * (c["H"] // 2) * (c["W"] // 2) for cin in stems) / 1e9
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+class Workload:
+    """One BASELINE configuration resident on this rank: model, optimizer, synthetic batch, and the training step."""
+
+    def __init__(self, c, device, rank, distributed, force):
+        from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+        from dmmfods_amd.optim import FusedAdam
+        from dmmfods_amd.parallel import GradAllReduce, broadcast_parameters
+        self.c = c
+        torch.manual_seed(123)  # identical weights on every rank (reference agent seed, H:179)
+        self.model = Dense_U_Net_lidar(make_config(c), compute_dtype=c["dtype"]).to(device).train()
+        self.opt = FusedAdam(self.model)
+        self.reducer = GradAllReduce(self.model, force=force) if distributed else None
+        if distributed:
+            broadcast_parameters(self.model, src=0, force=force)   # every rank starts from rank 0's weights and running statistics
+        self.rgb, self.lidar, self.tgt = synthetic_batch(c, device, seed=rank)
+        self.overlap_comm = not os.environ.get("DMM_NO_COMM_OVERLAP")
+        self.tail_events = None   # [(backward enqueued, collectives joined)] event pairs of the timed steps (N > 1)
+
+    def step(self):
+        from dmmfods_amd.parallel import GradAllReduce
+        m = self.model
+        with torch.no_grad():
+            m(self.rgb, self.lidar)
+        met = m.loss_backward(self.tgt)      # enqueues the whole backward; returns before the GPU has run it
+        if self.reducer is not None:
+            if self.tail_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()                  # = the end of this rank's backward on the compute stream
+            if self.overlap_comm:            # one all-reduce per gradient bucket, each behind the bucket's readiness event
+                GradAllReduce.wait(self.reducer.reduce_overlapped())
+            else:
+                self.reducer.all_reduce()
+            if self.tail_events is not None:
+                e1.record()                  # = the compute stream has joined the last collective: e1 - e0 = un-overlapped tail
+                self.tail_events.append((e0, e1))
+        self.opt.step()
+        return met
+
+    @property
+    def plan(self):
+        return self.model._last[0]
+
+
+def timed_region(w, steps, distributed, device):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; per-step durations from events recorded on the
+    compute stream between steps (no host synchronisation inside the region).  Returns (elapsed s, max over ranks; per-step ms)."""
+    import torch.distributed as dist
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    met = None
+    for i in range(steps):
+        met = w.step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return elapsed, per_step, met
+
+
+def step_stats(per_step):
+    return {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),
+            "p90": round(percentile(per_step, 0.9), 3), "n": len(per_step)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)    # SURVEY 8(d): >= 10 warm-up + >= 30 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--also", default=None, choices=sorted(CONFIGS) + ["none"],
+                    help="N > 1 only: a second workload measured after the main one and reported under 'also' (default c3, BASELINE's 8-GPU d121 configuration)")
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,6 +335,9 @@ def main():
     ap.add_argument("--table", action="store_true", help="also print the per-kernel-class table to stderr")
     ap.add_argument("--ops", type=int, default=0, help="print the N most expensive launches (per step) to stderr")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("DMM_FORCE_DIST"):
+        sys.exit(spawn_ranks(args.gpus))
 
     # Native libraries write to file descriptor 1 (RCCL prints its version banner there when the first communicator comes up).
     # The contract is ONE JSON line on stdout, so everything else that lands on fd 1 goes to stderr and the line is written to
@@ -226,6 +348,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to report a {world}-rank run as {args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
     distributed = world > 1 or bool(os.environ.get("DMM_FORCE_DIST"))  # the second form exercises the N>1 code path on one GPU
     # Rehearsal of the N > 1 code path on a ONE-GPU box (tests/test_dp_gpu.py): DMM_DIST_BACKEND=gloo DMM_DIST_SAME_DEVICE=1 puts
     # every rank on cuda:0 and exchanges through gloo (RCCL refuses two ranks on one device).  Never the measured configuration.
@@ -236,47 +361,27 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:   # (only the single-process DMM_FORCE_DIST form gets here without one)
+            os.environ["MASTER_PORT"] = str(free_port())
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dmmfods_amd import _lib
-    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
-    from dmmfods_amd.optim import FusedAdam
-    from dmmfods_amd.parallel import GradAllReduce, broadcast_parameters
 
     c = dict(CONFIGS[args.config])
     if args.dtype:
         c["dtype"] = args.dtype
     if args.batch:
         c["batch"] = args.batch
-    torch.manual_seed(123)  # identical weights on every rank (reference agent seed, H:179)
-    model = Dense_U_Net_lidar(make_config(c), compute_dtype=c["dtype"]).to(device).train()
-    opt = FusedAdam(model)
     force = world == 1 and distributed  # DMM_FORCE_DIST: the N > 1 code path, collectives included, on one GPU
-    reducer = GradAllReduce(model, force=force) if distributed else None
-    if distributed:
-        broadcast_parameters(model, src=0, force=force)   # every rank starts from rank 0's weights and running statistics
-    rgb, lidar, tgt = synthetic_batch(c, device, seed=rank)
-    overlap_comm = not os.environ.get("DMM_NO_COMM_OVERLAP")
-
-    def step():
-        with torch.no_grad():
-            model(rgb, lidar)
-        met = model.loss_backward(tgt)      # enqueues the whole backward; returns before the GPU has run it
-        if reducer is not None:
-            if overlap_comm:                # one all-reduce per gradient bucket, each behind the bucket's readiness event
-                GradAllReduce.wait(reducer.reduce_overlapped())
-            else:
-                reducer.all_reduce()
-        opt.step()
-        return met
+    w = Workload(c, device, rank, distributed, force)
+    step = w.step
 
     for _ in range(args.warmup):
         step()
-    plan = model._last[0]
+    plan = w.plan
     L = _lib.lib()
     full_classes, ops_list, dom_prefix = None, None, None
     if not args.no_profile:
@@ -289,7 +394,7 @@ def main():
         torch.cuda.synchronize()
         ops_list = [] if args.ops else None
         enc = {}
-        full_classes = collect_profile(model, plan, 1, ops_list, enc)
+        full_classes = collect_profile(w.model, plan, 1, ops_list, enc)
         if full_classes and rank == 0:
             dom_prefix = (dominant_class(full_classes)[0] + "/").encode()
         if distributed:
@@ -300,33 +405,52 @@ def main():
         # the event pairs are recorded in the first EVENT_PASSES steps of the timed region only (each pair costs ~5 us of stream time)
         _lib.check(L.dmm_plan_profile_begin(plan.handle, min(EVENT_PASSES, args.steps)))
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        met = step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        w.tail_events = []
+    elapsed, per_step, met = timed_region(w, args.steps, distributed, device)
     loss = met["loss_per_class"].sum().item()
+    comm = None
+    if distributed and w.tail_events:
+        tails = [a.elapsed_time(b) for a, b in w.tail_events]
+        bk = w.model.grad_buckets()
+        comm = {"backend": backend, "rccl_world": world if backend == "nccl" else None, "overlap": bool(w.overlap_comm),
+                "buckets": len(bk), "bucket_mb": [round(n * 4 / 2 ** 20, 1) for _, n in bk],
+                "all_reduce_mb_per_step": round(sum(n for _, n in bk) * 4 / 2 ** 20, 1),
+                # time the compute stream spent waiting for collectives after ITS OWN backward had finished (rank 0): the part of
+                # the exchange that backward did not hide, including the wait for slower ranks
+                "unoverlapped_tail_ms": step_stats(tails)}
+    w.tail_events = None
+
+    also = None
+    also_name = args.also or ("c3" if world > 1 and args.config == "c2" else "none")
+    if world > 1 and also_name != "none" and also_name != args.config:
+        # BASELINE's multi-GPU configurations are the mid-fusion networks; `value` stays on the 1-GPU workload so that the 1 -> N
+        # series is one weak-scaling curve, and the named 8-GPU configuration is measured right behind it on the same ranks
+        c2nd = dict(CONFIGS[also_name])
+        del w
+        torch.cuda.empty_cache()
+        w2 = Workload(c2nd, device, rank, distributed, force)
+        for _ in range(args.warmup):
+            w2.step()
+        w2.tail_events = []
+        el2, ps2, _ = timed_region(w2, args.steps, distributed, device)
+        tails2 = [a.elapsed_time(b) for a, b in w2.tail_events]
+        also = {"workload": c2nd["name"], "dtype": DTYPE_LABEL[c2nd["dtype"]], "value": round(c2nd["batch"] * world * args.steps / el2, 3),
+                "unit": "img/s", "ms_per_step": round(el2 / args.steps * 1e3, 3), "step_ms": step_stats(ps2),
+                "per_gpu_batch": c2nd["batch"], "unoverlapped_tail_ms": step_stats(tails2)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = c["batch"] * world * args.steps / elapsed
         roof, table = (None, None)
         if not args.no_profile and full_classes:
-            timed = collect_profile(model, plan, args.steps)
+            timed = collect_profile(None, plan, args.steps)
             roof, table = roofline_block(full_classes, c["dtype"], (args.config, c["batch"], DTYPE_LABEL[c["dtype"]]), timed)
             if ops_list:
                 ops_list.sort(reverse=True)
                 for ms_, lab, fl, by in ops_list[:args.ops]:
                     print(f"{ms_:9.3f} ms  {lab:48s} {fl / ms_ / 1e9 if ms_ else 0:8.1f} TF/s {by / ms_ / 1e6 if ms_ else 0:8.1f} GB/s", file=sys.stderr)
         fwd_flops_img = plan.flops_forward / c["batch"]
+        train_flops_img = 3 * fwd_flops_img - conv0_dgrad_gflop(c) * 1e9   # SURVEY 8(d) convention
         out = {
             "metric": metric_label(c),
             "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -336,13 +460,18 @@ def main():
                        "height": c["H"], "width": c["W"], "storage_dtype": c["dtype"], "accumulate": "fp32",
                        "parallelism": f"dp{world}", "weights": "random-init (reference init, seed 123)",
                        "fwd_conv_gflop_per_img": round(fwd_flops_img / 1e9, 1),
-                       "train_conv_gflop_per_img": round(3 * fwd_flops_img / 1e9, 1)},
+                       "train_conv_gflop_per_img": round(train_flops_img / 1e9, 1)},
+            "step_ms": step_stats(per_step),          # per-step durations (HIP events between steps on the compute stream)
             "final_loss_sum": loss,
-            "achieved_conv_tflops": round(3 * fwd_flops_img * value / 1e12, 2),
+            "achieved_conv_tflops": round(train_flops_img * value / 1e12, 2),
             # MFMA-only fraction of the step = (sum of conv FLOPs / dense MFMA peak) / measured step time
-            "mfma_only_frac_of_step": round(3 * fwd_flops_img * value / 1e12 / (world * PEAK_MFMA_TFLOPS[c["dtype"]]), 4),
+            "mfma_only_frac_of_step": round(train_flops_img * value / 1e12 / (world * PEAK_MFMA_TFLOPS[c["dtype"]]), 4),
             "roofline": roof,
         }
+        if comm is not None:
+            out["comm"] = comm
+        if also is not None:
+            out["also"] = [also]
         if not args.no_profile and full_classes and enc.get("ms"):
             # forward time of the encoder's 1x1 convolutions in the serial per-launch pass vs the dense MFMA peak
             out["encoder_1x1"] = {"fwd_ms": round(enc["ms"], 3), "fwd_gflop": round(enc["flops"] / 1e9, 1),

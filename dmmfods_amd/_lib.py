@@ -92,6 +92,9 @@ def lib():
     L.dmm_conv_forward.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     L.dmm_conv_wgrad.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     L.dmm_conv_dgrad.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dmm_conv_wgrad_ex.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.dmm_conv_dgrad_ex.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.dmm_conv1x1_backward_fused.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -103,7 +106,7 @@ EXPORTS = [
     "dmm_plan_loss_metrics", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
     "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
-    "dmm_conv_dgrad",
+    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused",
 ]
 
 

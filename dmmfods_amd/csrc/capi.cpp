@@ -199,8 +199,8 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, lst); break;
       case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, lst); break;
       case OP_CONVERT: e = launch_convert_input(o.cv, dt, lst); break;
-      case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst); break;
-      case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst); break;
+      case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst, o.impl); break;
+      case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst, o.impl); break;
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
       case OP_JOIN: join(); break;  // the main stream waits for what the side stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
@@ -489,8 +489,9 @@ size_t dmm_conv_scratch_bytes(const dmm_conv_desc* d) {
   PackDesc* dd; int* dp; int tr;
   size_t fwd = layout_fwd(d, g, nullptr, nullptr, nullptr, packs, &dd, &dp, prefix, tr);
   // dgrad pack: [chunks][rup(Cin,32)][BK] with K' = R*S*rup(Cout,8)
-  const size_t dg = (size_t)((d->R * d->S * rup(d->Cout, 8) + g.BK - 1) / g.BK + 16) * rup(d->Cin, 32) * g.BK * g.esz;
-  return fwd + dg + 4096;
+  const size_t dg = (size_t)((d->R * d->S * rup(d->Cout, 8) + g.BK - 1) / g.BK + 16) * rup(d->Cin, 128) * g.BK * g.esz;
+  // + the fp32 dgrad-shaped packed gradient of the transposed-form weight gradient, zero tables, descriptors
+  return fwd + dg + 2 * dg + (size_t)rup(d->Cout, 8) * 8 + 8192;
 }
 
 static void fill_one_seg(Seg& s, const dmm_conv_desc* d, const OneConv& g, const void* x, const float* scale, const float* shift,
@@ -532,16 +533,79 @@ int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, cons
   return DMM_OK;
 }
 
-int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, float* dw, void* scratch,
-                   void* stream) {
+// dy_eff = dy + q[c] + r[c] * yfwd (the deferred BatchNorm-backward correction of the plan's gradient buffers) when q != NULL
+static void set_eff_grad(Seg& s, const void* yfwd, int ldy, const float* q, const float* r, const float* zeros) {
+  if (q == nullptr) return;
+  s.src2 = yfwd; s.ld2 = ldy; s.q = q; s.r = r; s.ql = zeros; s.rl = zeros;
+}
+
+// the dgrad-shaped pack of a convolution: [chunks over (tap, output channel)][Npad input channels][BK]
+static PackDesc dgrad_pack_desc(const dmm_conv_desc* d, const OneConv& g, const std::vector<Tap>& taps, const float* w, int npad) {
+  PackDesc pd;
+  memset(&pd, 0, sizeof(pd));
+  const long long RS = (long long)d->R * d->S;
+  pd.w = w;
+  pd.N = d->Cin; pd.Npad = npad; pd.nseg = 1;
+  if (!d->transposed) { pd.sn = RS; pd.sk = d->Cin * RS; } else { pd.sn = (long long)d->Cout * RS; pd.sk = RS; }
+  pd.st = 1;
+  fill_pack_seg(pd.seg[0], taps, d->Cout, rup(d->Cout, 8), 0, g.BK);
+  return pd;
+}
+
+int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, const void* yfwd,
+                      const float* q, const float* r, int transposed_form, float* dw, void* scratch, void* stream) {
   OneConv g;
   if (!d || !geometry(d, g)) return fail(DMM_ERR_INVALID, "unsupported conv descriptor");
+  if ((q != nullptr) != (r != nullptr) || (q != nullptr && yfwd == nullptr)) return fail(DMM_ERR_INVALID, "q, r and yfwd come together");
   hipStream_t st = (hipStream_t)stream;
+  const size_t wn = (size_t)d->Cin * d->Cout * d->R * d->S;
+  if (transposed_form) {
+    // taps on the gradient side (wgrad.hip "transposed form", what the plan builds for thin outputs: plan.cpp finish_conv):
+    // the result has the shape of the data-gradient pack and is scattered into the master layout through that descriptor
+    if (d->transposed || d->mode != 0 || d->stride != 1 || d->R * d->S <= 1 || !d->bn_relu)
+      return fail(DMM_ERR_INVALID, "the transposed form serves unit-stride multi-tap convolutions behind BN+ReLU");
+    const std::vector<Tap> taps = taps_conv_dgrad(d->R, d->S, d->pad);
+    const int cs = g.Cst;
+    const int npad = rup(cs, cs >= 384 || cs % 128 == 0 ? 128 : (cs >= 64 ? 64 : 32));
+    Scratch S{(uint8_t*)scratch};
+    PackDesc* dd = (PackDesc*)S.take(sizeof(PackDesc));
+    int* dp = (int*)S.take(sizeof(int));
+    float* zeros = (float*)S.take((size_t)rup(d->Cout, 8) * sizeof(float) + 64);
+    PackDesc pd = dgrad_pack_desc(d, g, taps, dw, npad);
+    const size_t elems = (size_t)pd.seg[0].nchunks * pd.Npad * g.BK;
+    pd.dpack = (float*)S.take(elems * sizeof(float));
+    pd.gw = dw;
+    if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
+    HIPCHK(hipMemsetAsync(scratch, 0, S.off, st));
+    int zero = 0;
+    HIPCHK(hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dp, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = 1;
+    Seg& sq = a.seg[0];  // Q: the output gradient under the flipped taps
+    sq.src = dy; sq.ld = d->Cout; sq.Hs = g.Hout; sq.Ws = g.Wout; sq.C = rup(d->Cout, 8); sq.Cpad = sq.C; sq.mode = G_PLAIN; sq.istride = 1;
+    set_eff_grad(sq, yfwd, d->Cout, q, r, zeros);
+    fill_seg_taps(sq, taps, g.BK);
+    a.B = d->B; a.Ho = g.Ho; a.Wo = g.Wo; a.M = d->B * g.Ho * g.Wo;
+    fill_one_seg(a.dy, d, g, x, scale, shift, taps_conv(1, 1, 0));  // P: the activated input, once
+    a.dy.istride = 1;
+    a.N = g.Cst; a.Npad = pd.Npad;
+    a.dpack = (float*)pd.dpack;
+    HIPCHK(launch_wgrad(a, d->dtype, d->use_mfma != 0, st));
+    HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
+    HIPCHK(launch_unpack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, 1.0f, st));
+    return DMM_OK;
+  }
   std::vector<PackDesc> packs;
   std::vector<int> prefix;
   PackDesc* dd; int* dp; int total_rows;
   const size_t used = layout_fwd(d, g, (uint8_t*)scratch, dw /*unused as w*/, dw, packs, &dd, &dp, prefix, total_rows);
-  HIPCHK(hipMemsetAsync(scratch, 0, used, st));
+  Scratch S{(uint8_t*)scratch, used};
+  float* zeros = (float*)S.take((size_t)rup(d->Cout, 8) * sizeof(float) + 64);
+  if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
+  HIPCHK(hipMemsetAsync(scratch, 0, S.off, st));
   HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -554,52 +618,51 @@ int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const 
     a.dy.src = dy; a.dy.ld = d->Cout; a.dy.Hs = g.Hout; a.dy.Ws = g.Wout; a.dy.C = rup(d->Cout, 8); a.dy.Cpad = a.dy.C;
     a.dy.mode = G_PLAIN; a.dy.istride = g.ostride; a.dy.ntaps = 1; a.dy.nchunks = 1;
     a.dy.taps[0] = (short)((g.phase_xy[ph].first & 0xff) | ((g.phase_xy[ph].second & 0xff) << 8));
+    set_eff_grad(a.dy, yfwd, d->Cout, q, r, zeros);
     a.N = d->Cout; a.Npad = packs[ph].Npad;
     a.dpack = (float*)packs[ph].dpack;
     HIPCHK(launch_wgrad(a, d->dtype, d->use_mfma != 0, st));
   }
-  const size_t wn = (size_t)d->Cin * d->Cout * d->R * d->S;
   HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
   HIPCHK(launch_unpack(dd, dp, (int)packs.size(), total_rows, d->dtype, 1.0f, st));
   return DMM_OK;
 }
 
-int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift, void* gx,
-                   double* red, void* scratch, void* stream) {
-  OneConv g;
-  if (!d || !geometry(d, g) || !d->bn_relu) return fail(DMM_ERR_INVALID, "unsupported conv descriptor (dgrad needs bn_relu)");
-  if (d->mode == 0 && !d->transposed && d->stride != 1) return fail(DMM_ERR_INVALID, "strided conv dgrad is not on the hot path");
-  hipStream_t st = (hipStream_t)stream;
+int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, float* dw, void* scratch,
+                   void* stream) {
+  return dmm_conv_wgrad_ex(d, x, dy, scale, shift, nullptr, nullptr, nullptr, 0, dw, scratch, stream);
+}
+
+// Fills the data-gradient launch of one convolution (EPI_BNBWD) and packs its weights; shared by dmm_conv_dgrad_ex and
+// dmm_conv1x1_backward_fused.
+static int build_dgrad(const dmm_conv_desc* d, const OneConv& g, const void* x, const void* dy, const float* w, const float* scale,
+                       const float* shift, const void* yfwd, const float* q, const float* r, void* gx, int accumulate, double* red,
+                       Scratch& S, int npad, ConvArgs& a, hipStream_t st) {
   std::vector<Tap> taps;
   int istride = 1, rH = d->H, rW = d->W, pool2 = 0, ostride = 1;
   if (d->transposed) { taps = taps_convT_dgrad(); istride = 2; }
   else if (d->mode == 2) { taps = taps_conv(1, 1, 0); rH = d->H / 2; rW = d->W / 2; pool2 = 1; ostride = 2; }
   else if (d->mode == 1) { taps = taps_up2_merged_dgrad(); istride = 2; }
   else taps = taps_conv_dgrad(d->R, d->S, d->pad);
-  Scratch S{(uint8_t*)scratch};
   PackDesc* dd = (PackDesc*)S.take(sizeof(PackDesc));
   int* dp = (int*)S.take(sizeof(int));
-  PackDesc pd;
-  memset(&pd, 0, sizeof(pd));
-  const long long RS = (long long)d->R * d->S;
-  pd.w = w;
-  pd.N = d->Cin; pd.Npad = rup(d->Cin, 32); pd.nseg = 1;
-  if (!d->transposed) { pd.sn = RS; pd.sk = d->Cin * RS; } else { pd.sn = (long long)d->Cout * RS; pd.sk = RS; }
-  pd.st = 1;
-  const int kc = rup(d->Cout, 8);
-  fill_pack_seg(pd.seg[0], taps, d->Cout, kc, 0, g.BK);
+  float* zeros = (float*)S.take((size_t)rup(d->Cout, 8) * sizeof(float) + 64);
+  PackDesc pd = dgrad_pack_desc(d, g, taps, w, npad);
   pd.dst = S.take((size_t)pd.seg[0].nchunks * pd.Npad * g.BK * g.esz);
+  if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
   int zero = 0;
+  HIPCHK(hipMemsetAsync(zeros, 0, (size_t)rup(d->Cout, 8) * sizeof(float) + 64, st));
   HIPCHK(hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(dp, &zero, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(launch_pack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, st));
   HIPCHK(hipMemsetAsync(red, 0, 2 * d->Cin * sizeof(double), st));
-  ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.nseg = 1;
   Seg& s = a.seg[0];
+  const int kc = rup(d->Cout, 8);
   s.src = dy; s.ld = d->Cout; s.Hs = g.Hout; s.Ws = g.Wout; s.C = kc; s.Cpad = kc; s.mode = G_PLAIN; s.istride = istride;
+  set_eff_grad(s, yfwd, d->Cout, q, r, zeros);
   fill_seg_taps(s, taps, g.BK);
   a.B = d->B; a.Ho = rH; a.Wo = rW; a.M = d->B * rH * rW;
   a.wpack = pd.dst; a.N = d->Cin; a.Npad = pd.Npad;
@@ -607,8 +670,71 @@ int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const 
   a.bx = x; a.ldbx = d->Cin; a.bscale = scale; a.bshift = shift;
   a.bmean = shift + d->Cin; a.binvstd = shift + 2 * d->Cin;  // test entry point: mean / invstd follow `shift`
   a.red1 = red; a.red2 = red + d->Cin;
-  a.accumulate = 0; a.pool2 = pool2;
+  a.accumulate = accumulate ? 1 : 0; a.pool2 = pool2;
+  return DMM_OK;
+}
+
+int dmm_conv_dgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
+                      const void* yfwd, const float* q, const float* r, void* gx, int accumulate, double* red, void* scratch,
+                      void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g) || !d->bn_relu) return fail(DMM_ERR_INVALID, "unsupported conv descriptor (dgrad needs bn_relu)");
+  if (d->mode == 0 && !d->transposed && d->stride != 1) return fail(DMM_ERR_INVALID, "strided conv dgrad is not on the hot path");
+  if ((q != nullptr) != (r != nullptr) || (q != nullptr && yfwd == nullptr)) return fail(DMM_ERR_INVALID, "q, r and yfwd come together");
+  hipStream_t st = (hipStream_t)stream;
+  Scratch S{(uint8_t*)scratch};
+  ConvArgs a;
+  // column tile of the plan (plan.cpp add_pack): 128 once the padding waste is <= 25 %, else 64, else 32
+  const int cs = g.Cst;
+  const int npad = rup(cs, cs >= 384 || cs % 128 == 0 ? 128 : (cs >= 64 ? 64 : 32));
+  const int rc = build_dgrad(d, g, x, dy, w, scale, shift, yfwd, q, r, gx, accumulate, red, S, npad, a, st);
+  if (rc) return rc;
   HIPCHK(launch_igemm(a, d->dtype, EPI_BNBWD, d->use_mfma != 0, st));
+  return DMM_OK;
+}
+
+int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift, void* gx,
+                   double* red, void* scratch, void* stream) {
+  return dmm_conv_dgrad_ex(d, x, dy, w, scale, shift, nullptr, nullptr, nullptr, gx, 0, red, scratch, stream);
+}
+
+int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale,
+                               const float* shift, const void* yfwd, const float* q, const float* r, void* gx, int accumulate,
+                               float* dw, double* red, void* scratch, void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g) || !d->bn_relu || d->R != 1 || d->S != 1 || d->stride != 1 || d->transposed || d->mode != 0)
+    return fail(DMM_ERR_INVALID, "the fused backward serves 1x1 unit-stride convolutions behind BN+ReLU");
+  if ((q != nullptr) != (r != nullptr) || (q != nullptr && yfwd == nullptr)) return fail(DMM_ERR_INVALID, "q, r and yfwd come together");
+  hipStream_t st = (hipStream_t)stream;
+  // forward-shaped packed gradient first (its descriptor scatters dW into the master layout), then the data-gradient launch
+  std::vector<PackDesc> packs;
+  std::vector<int> prefix;
+  PackDesc* dd; int* dp; int total_rows;
+  const size_t used = layout_fwd(d, g, (uint8_t*)scratch, dw, dw, packs, &dd, &dp, prefix, total_rows);
+  HIPCHK(hipMemsetAsync(scratch, 0, used, st));
+  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  Scratch S{(uint8_t*)scratch, used};
+  Bw1Args b;
+  memset(&b, 0, sizeof(b));
+  const int cs = g.Cst;
+  const int npad = rup(cs, cs >= 384 || cs % 128 == 0 ? 128 : (cs >= 64 ? 64 : 32));
+  const int rc = build_dgrad(d, g, x, dy, w, scale, shift, yfwd, q, r, gx, accumulate, red, S, npad, b.c, st);
+  if (rc) return rc;
+  WgradArgs wa;  // the weight-gradient launch the plan would have emitted: only to test the pair's eligibility
+  memset(&wa, 0, sizeof(wa));
+  wa.nseg = 1;
+  fill_one_seg(wa.seg[0], d, g, x, scale, shift, g.phase_taps[0]);
+  wa.B = d->B; wa.Ho = g.Ho; wa.Wo = g.Wo; wa.M = d->B * g.Ho * g.Wo;
+  wa.dy = b.c.seg[0];
+  wa.N = d->Cout; wa.Npad = packs[0].Npad;
+  wa.dpack = (float*)packs[0].dpack;
+  if (!bw1_eligible(wa, b.c, d->dtype)) return fail(DMM_ERR_INVALID, "not a pair bw1.hip fuses (16-bit storage, 128 output channels, Cin % 32 == 0)");
+  b.dpack = wa.dpack; b.dNpad = wa.Npad; b.wC = wa.seg[0].C;
+  HIPCHK(launch_bw1(b, d->dtype, st));
+  const size_t wn = (size_t)d->Cin * d->Cout;
+  HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
+  HIPCHK(launch_unpack(dd, dp, (int)packs.size(), total_rows, d->dtype, 1.0f, st));
   return DMM_OK;
 }
 

@@ -113,6 +113,18 @@ struct WgradArgs {
   int kgroups;         // number of K groups (each WG_CHUNKS chunks)
 };
 
+// Kernel family of a convolution / weight-gradient launch.  A plan decides it ONCE per launch when it is built (igemm_pick /
+// wgrad_pick walk the dispatch without launching and honour the dmm_set_option switches of that moment) and the executor
+// dispatches from the recorded value, so a plan's labels, its profile classes and the kernels it runs cannot drift apart when an
+// option is toggled afterwards.  IMPL_AUTO (the single-kernel test entry points): decide at the call.
+enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG };
+struct LaunchCtl {
+  bool dry = false;      // walk the eligibility tests, launch nothing
+  int impl = IMPL_AUTO;  // the one family allowed to take the launch (IMPL_AUTO: every enabled family, in dispatch order)
+};
+extern thread_local LaunchCtl g_ctl;  // (defined in pointwise.hip)
+inline bool family_on(bool enabled, int family) { return g_ctl.impl == IMPL_AUTO ? enabled : g_ctl.impl == family; }
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }

@@ -30,6 +30,10 @@
 namespace dmm {
 
 constexpr int C3_TH = 8, C3_TW = 16;
+#ifndef C3_DBG
+#define C3_DBG 0  // timing experiments only (experiment builds: -DC3_DBG=n; the shipped library carries no ablation switch): 1 halo
+                  // loads hit one line, 2 no MFMA, 4 no weight DMA, 8 no epilogue, 16 no global statistics atomics, 32 no statistics
+#endif
 constexpr int C3_WRING = 3;  // weight ring slots
 
 struct Conv3Args {
@@ -37,8 +41,6 @@ struct Conv3Args {
   int tiles_y, tiles_x;
   int dymin0, dxmin0;  // smallest tap offsets of segment 0 (its halo starts there)
   int dymin1, dxmin1;  // ... of the raw-input segment (stride-2 source)
-  int dbg;             // timing experiments (DMM_C3_DBG): 1 halo loads hit one line, 2 no MFMA, 4 no weight DMA, 8 no epilogue,
-                       // 16 no global statistics atomics, 32 no statistics at all
 };
 
 // CS = 16-byte channel slots per pixel of the wide segment (C = 8 CS, a multiple of 32; 0: no wide segment); SPAN = its tap
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned wdst0 = __builtin_amdgcn_readfirstlane(lds0 + SM::HALO0 + SM::HALO1 + wave * NPW * 1024);
   auto issue_w = [&](int grp) {
-    if (g.dbg & 4) return;
+    if (C3_DBG & 4) return;
     const unsigned dst = wdst0 + (grp % C3_WRING) * SM::WSLOT;
     const T* src = wp + (size_t)grp * (GC * BN * 32);
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     // branch-free: a slot outside the picture loads a clamped (valid) address and is zeroed when the image is written; a
     // conditional load would make the compiler wait for each load before the next branch
     const int cy = min(max(sy, 0), sg.Hs - 1), cx = min(max(sx, 0), sg.Ws - 1);
-    const size_t pix = (g.dbg & 1) ? 0 : (size_t)(b * sg.Hs + cy) * sg.Ws + cx;
+    const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg.Hs + cy) * sg.Ws + cx;
     raw[i] = *(const V*)(src + pix * sg.ld);
     if constexpr (PRO == 2) raw2[i] = *(const V*)(src2 + pix * sg.ld2);
   }
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       const int sy = TSTR * y0 + g.dymin1 + hy, sx = TSTR * x0 + g.dxmin1 + hx;
       okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
       const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
-      const size_t pix = (g.dbg & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
+      const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
       rawb[i] = *(const V*)((const T*)sg1.src + pix * sg1.ld);
     }
   }
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   for (int grp = 0; grp < NGRP; ++grp) {
     if (grp + 2 < NGRP) issue_w(grp + 2);  // ring slot (grp + 2) % 3 was last read during grp - 1: all waves are past its barrier
     const unsigned char* Bp = wring + (grp % C3_WRING) * SM::WSLOT;
-    if (!(g.dbg & 2)) {
+    if (!(C3_DBG & 2)) {
 #pragma unroll
       for (int gc = 0; gc < GC; ++gc) {
         const int ck = grp * GC + gc;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if ((g.dbg & 8) && acc[0][0] != 123.f) return;
+  if ((C3_DBG & 8) && acc[0][0] != 123.f) return;
   // all waves are past the last barrier: the images and the ring are dead, reuse them for staging
   T* Cs = (T*)smem;
   constexpr int CPITCH = BN + 8;
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       if (pix < 0 || !colvalid) continue;
       *(V*)(out + (size_t)pix * a.ldo + n) = *(const V*)(Cs + row * CPITCH + cv * SLOT);
     }
-    if (a.stat_sum == nullptr || (g.dbg & 32)) return;
-    if (!(g.dbg & 16) && tid < 2 * BN) {
+    if (a.stat_sum == nullptr || (C3_DBG & 32)) return;
+    if (!(C3_DBG & 16) && tid < 2 * BN) {
       const int col = tid % BN, which = tid / BN;
       if (col < a.N) {
         double s = 0.0;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       }
       if (gout != nullptr) *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
     }
-    if (g.dbg & 32) return;
+    if (C3_DBG & 32) return;
     // per-channel reductions: lanes -> LDS (fp64) -> one fp64 atomic per channel and workgroup (see igemm.hip)
 #pragma unroll
     for (int i = 0; i < SLOT; ++i) {
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       }
     }
     __syncthreads();
-    if (!(g.dbg & 16) && tid < BN && tid < a.N) {
+    if (!(C3_DBG & 16) && tid < BN && tid < a.N) {
       const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
       atomic_add_f64(a.red1 + rep + tid, red[tid]);
       atomic_add_f64(a.red2 + rep + tid, red[BN + tid]);
@@ -407,13 +409,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 static bool g_conv3 = getenv("DMM_NO_CONV3") == nullptr;
 void conv3_set_enabled(bool on) { g_conv3 = on; }
 
-static thread_local bool g_c3_dry = false;  // conv3_handles(): walk the dispatch without launching
 
 template <typename T, int CS, int SPAN, int TSPAN, int TSTR, int NT, int GC, int EPI, int PRO>
 static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
   typedef Conv3Cfg<T, CS, SPAN, TSPAN, TSTR, NT, GC> SM;
   static_assert(SM::bytes <= 80 * 1024, "two workgroups per CU");
-  if (g_c3_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   auto kern = conv3_kernel<T, CS, SPAN, TSPAN, TSTR, NT, GC, EPI, PRO>;
   static bool attr_done = false;
   if (SM::bytes > 48 * 1024 && !attr_done) {
@@ -470,7 +471,7 @@ static bool tap_box(const Seg& sg, int& dymin, int& dxmin, int& span) {
 // Returns hipErrorNotSupported when the layer is not one of the shapes built (16-bit storage, unit-stride multi-tap segment of
 // C % 32 == 0 channels on the row grid, optionally the 8-channel stride-2 raw-input segment of the head).
 hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
-  if (!g_conv3 || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2 || a.pool2 || (epi != EPI_STORE && epi != EPI_BNBWD)) return hipErrorNotSupported;
+  if (!family_on(g_conv3, IMPL_CONV3) || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2 || a.pool2 || (epi != EPI_STORE && epi != EPI_BNBWD)) return hipErrorNotSupported;
   const Seg& sg = a.seg[0];
   if (a.Npad % 32 || a.Npad > 128) return hipErrorNotSupported;
   Conv3Args g;
@@ -501,20 +502,19 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
   g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
   g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
-  static const int dbg = getenv("DMM_C3_DBG") ? atoi(getenv("DMM_C3_DBG")) : 0;
-  g.dbg = dbg;
   const int nt = a.Npad / 32;
   static const bool trace = getenv("DMM_C3_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);
+  if (trace && !g_ctl.dry) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);
   return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, tspan, tstr, nt, st)
                          : launch_c3_type<bf16>(g, epi, pro, cs, span, tspan, tstr, nt, st);
 }
 
 // Does launch_conv3 take this launch?  (the plan labels its launches by the kernel family that runs them)
 bool conv3_handles(const ConvArgs& a, int dtype, int epi) {
-  g_c3_dry = true;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
   const hipError_t e = launch_conv3(a, dtype, epi, nullptr);
-  g_c3_dry = false;
+  g_ctl = keep;
   return e == hipSuccess;
 }
 

@@ -498,7 +498,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
 static bool g_cvp = getenv("DMM_NO_CVP") == nullptr;
 void cvp_set_enabled(bool on) { g_cvp = on; }
 
-static thread_local bool g_cvp_dry = false;
 
 template <typename T, int NTAP>
 static hipError_t launch_cvp_t(const CvpArgs& g, int nwg, hipStream_t st) {
@@ -518,7 +517,7 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st);
 // Takes a forward launch (EPI_STORE) with one plain segment of a multiple of 128 BN+ReLU-normalised input channels whose 1, 2 or
 // 4 taps lie in a 2x2 box, a multiple of 128 padded output columns, 16-bit storage.  Returns hipErrorNotSupported otherwise.
 hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
-  if (!g_cvp || dtype == DT_F32) return hipErrorNotSupported;
+  if (!family_on(g_cvp, IMPL_CVP) || dtype == DT_F32) return hipErrorNotSupported;
   if (epi == EPI_BNBWD) return launch_cvd(a, dtype, st);
   if (epi != EPI_STORE || a.nseg != 1 || a.pool2) return hipErrorNotSupported;
   const Seg& x = a.seg[0];
@@ -533,7 +532,7 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
     dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax; dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
   }
   if (dymax - dymin > 1 || dxmax - dxmin > 1) return hipErrorNotSupported;
-  if (g_cvp_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   CvpArgs g;
   g.c = a;
   g.dymin = dymin; g.dxmin = dxmin;
@@ -579,7 +578,7 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
     if (cnt[cls] >= cap) return hipErrorNotSupported;
     g.tapidx[(up2 ? base16 : base9)[cls] + cnt[cls]++] = t;
   }
-  if (g_cvp_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   g.c = a;
   g.tiles_y = (a.Ho + CP_TH - 1) / CP_TH;
   g.tiles_x = (a.Wo + CP_TW - 1) / CP_TW;
@@ -590,9 +589,10 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 bool cvp_handles(const ConvArgs& a, int dtype, int epi) {
-  g_cvp_dry = true;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
   const hipError_t e = launch_cvp(a, dtype, epi, nullptr);
-  g_cvp_dry = false;
+  g_ctl = keep;
   return e == hipSuccess;
 }
 

@@ -460,7 +460,8 @@ hipError_t launch_halo_f32(const HaloArgs& h, int epi, hipStream_t st);  // halo
 // Returns hipErrorNotSupported when the layer is not eligible.
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   HaloArgs h;
-  if (dtype == DT_BF16) return hipErrorNotSupported;  // bf16 layers take the generic / thin kernels
+  static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;
+  if (!family_on(!no_halo, IMPL_HALO) || dtype == DT_BF16) return hipErrorNotSupported;  // bf16 layers take the generic / thin kernels
   if (a.pool2 || !halo_plan(a, dtype, epi, h)) return hipErrorNotSupported;
   if (epi != EPI_BNBWD && a.seg[0].q != nullptr) return hipErrorNotSupported;
   if (epi == EPI_STORE && a.Npad > 64) return hipErrorNotSupported;
@@ -470,6 +471,8 @@ hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   // other eligible layers stay on igemm unless DMM_HALO_ALL is set.
   static const bool all = getenv("DMM_HALO_ALL") != nullptr;
   if (!all && epi != EPI_LOGITS) return hipErrorNotSupported;
+  if (g_ctl.dry) return (epi == EPI_STORE && (h.c.Npad == 64 || h.c.Npad == 32)) || (epi == EPI_LOGITS && h.c.Npad == 32) ||
+                        (epi == EPI_BNBWD && (h.c.Npad == 128 || h.c.Npad == 64 || h.c.Npad == 32)) ? hipSuccess : hipErrorNotSupported;
   return dtype == DT_F16 ? launch_halo_type<f16>(h, epi, st) : launch_halo_f32(h, epi, st);
 }
 #endif

@@ -726,28 +726,49 @@ template hipError_t launch_igemm_type<bf16>(const ConvArgs&, int, bool, hipStrea
 extern template hipError_t launch_igemm_type<float>(const ConvArgs&, int, bool, hipStream_t);
 extern template hipError_t launch_igemm_type<bf16>(const ConvArgs&, int, bool, hipStream_t);
 
-hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st) {
+// The special-case families in dispatch order; `took` = the family that accepted the launch (IMPL_GENERIC: none did).
+static hipError_t dispatch_special(const ConvArgs& a, int dtype, int epi, hipStream_t st, int& took) {
+  hipError_t e;
+  took = IMPL_THIN;   // few output channels x many taps: gather once, reduce the taps in LDS
+  if ((e = launch_thin_logits(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_CONV3;  // 3x3 convolutions of the dense layers (16-bit storage): LDS halo tile, prologue once per element
+  if ((e = launch_conv3(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_CVP;    // forward of the ConvTranspose parity phases: halo tile per 128-channel group, a tap is a fragment address
+  if ((e = launch_cvp(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_HALO;   // multi-tap layers whose weights fit in LDS may take the halo-tile kernel
+  if ((e = launch_halo(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_GENERIC;
+  return hipErrorNotSupported;
+}
+
+// impl = IMPL_AUTO: every enabled family may take the launch (the single-kernel test entry points); otherwise the family a plan
+// recorded for this launch when it was built (igemm_pick), whatever the option switches say now.
+hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st, int impl) {
   if (a.M <= 0) return hipSuccess;
-  if (mfma) {  // few output channels x many taps: gather once, reduce the taps in LDS
-    const hipError_t e = launch_thin_logits(a, dtype, epi, st);
-    if (e != hipErrorNotSupported) return e;
-  }
-  if (mfma) {  // 3x3 convolutions of the dense layers (16-bit storage): LDS halo tile, prologue once per element
-    const hipError_t e = launch_conv3(a, dtype, epi, st);
-    if (e != hipErrorNotSupported) return e;
-  }
-  if (mfma) {  // forward of the ConvTranspose parity phases: halo tile per 128-channel group, a tap is a fragment address
-    const hipError_t e = launch_cvp(a, dtype, epi, st);
-    if (e != hipErrorNotSupported) return e;
-  }
-  static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;
-  if (mfma && !no_halo) {  // multi-tap layers whose weights fit in LDS may take the halo-tile kernel
-    const hipError_t e = launch_halo(a, dtype, epi, st);
+  if (mfma && impl != IMPL_GENERIC) {
+    const LaunchCtl keep = g_ctl;
+    g_ctl.dry = false;
+    g_ctl.impl = impl;
+    int took;
+    const hipError_t e = dispatch_special(a, dtype, epi, st, took);
+    g_ctl = keep;
     if (e != hipErrorNotSupported) return e;
   }
   if (dtype == DT_F16) return launch_igemm_type<f16>(a, epi, mfma, st);
   if (dtype == DT_BF16) return launch_igemm_type<bf16>(a, epi, mfma, st);
   return launch_igemm_type<float>(a, epi, mfma, st);
+}
+
+// Which family launch_igemm(..., IMPL_AUTO) would run for this launch right now (nothing is launched).
+int igemm_pick(const ConvArgs& a, int dtype, int epi, bool mfma) {
+  if (!mfma) return IMPL_GENERIC;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
+  g_ctl.impl = IMPL_AUTO;
+  int took;
+  dispatch_special(a, dtype, epi, nullptr, took);
+  g_ctl = keep;
+  return took;
 }
 #endif
 

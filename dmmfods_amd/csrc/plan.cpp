@@ -536,9 +536,10 @@ struct Builder {
       {
         char cb[32];
         const double np = (double)c.phases.size();
-        const bool c3 = d.use_mfma && conv3_handles(a, dtype, c.epi);
-        const bool cp = d.use_mfma && !c3 && cvp_handles(a, dtype, c.epi);
-        tag(o, ncls(c.epi == EPI_LOGITS ? "igemm.logits" : (c3 ? "conv3.store" : (cp ? "cvp.store" : "igemm.store")), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        o.impl = igemm_pick(a, dtype, c.epi, d.use_mfma != 0);
+        const bool c3 = o.impl == IMPL_CONV3, cp = o.impl == IMPL_CVP;
+        const char* lcls = o.impl == IMPL_THIN ? "thin.logits" : (o.impl == IMPL_HALO ? "halo.logits" : "igemm.logits");
+        tag(o, ncls(c.epi == EPI_LOGITS ? lcls : (c3 ? "conv3.store" : (cp ? "cvp.store" : (o.impl == IMPL_HALO ? "halo.store" : "igemm.store"))), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + out_bytes(c)) / np + w_bytes(c) / np);
       }
       if (c.epi == EPI_LOGITS) {
@@ -629,7 +630,8 @@ struct Builder {
       a.N = c.seg[0].C; a.Npad = pd.Npad;
       a.dpack = (float*)pd.dpack;
       char cb[32];
-      tag(o, ncls((d.use_mfma && wg3_handles(a, dtype)) ? "wg3" : ((d.use_mfma && wg5_handles(a, dtype)) ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
+      o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
+      tag(o, ncls(o.impl == IMPL_WG3 ? "wg3" : (o.impl == IMPL_WG5 ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
           src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
     } else
     for (auto& ph : c.phases) {
@@ -648,7 +650,8 @@ struct Builder {
         char cb[32];
         const double np = (double)c.phases.size();
         // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
-        tag(o, ncls((d.use_mfma && wgp_handles(a, dtype)) ? "wgp" : ((d.use_mfma && wg5_handles(a, dtype)) ? "wg5" : "wgrad"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
+        tag(o, ncls(o.impl == IMPL_WGP ? "wgp" : (o.impl == IMPL_WG5 ? "wg5" : "wgrad"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
@@ -707,9 +710,9 @@ struct Builder {
         // reads: output gradient (+ forward output for the correction), x for the ReLU mask, (old gradient); writes gradient
         const double srcb = (double)sb.B * sb.H * sb.W * sr.C * esz;
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
-        const bool c3 = d.use_mfma && conv3_handles(a, dtype, EPI_BNBWD);
-        const bool cp = d.use_mfma && !c3 && cvp_handles(a, dtype, EPI_BNBWD);
-        tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : "igemm.bnbwd"), pd.Npad, cb), short_name(c.wname), segf,
+        o.impl = igemm_pick(a, dtype, EPI_BNBWD, d.use_mfma != 0);
+        const bool c3 = o.impl == IMPL_CONV3, cp = o.impl == IMPL_CVP;
+        tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : (o.impl == IMPL_HALO ? "halo.bnbwd" : "igemm.bnbwd")), pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
       if (pending_w) {

@@ -44,6 +44,7 @@ struct Op {
   int epi;
   int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it)
   int signal;      // gradient bucket event to record behind this launch on the stream it ran on (-1: none)
+  int impl;        // kernel family (enum Impl) chosen for this launch when the plan was built
   double flops;    // algorithmic 2*MACs of this launch (reference formulation)
   double bytes;    // algorithmic HBM bytes: every operand read once, every result written once
   char label[56];  // kernel class / layer
@@ -62,7 +63,7 @@ struct Op {
     ApplyCorrArgs ac;
     Bw1Args b1;
   };
-  Op() : kind(0), epi(0), leaf(0), signal(-1), flops(0), bytes(0) { label[0] = 0; }
+  Op() : kind(0), epi(0), leaf(0), signal(-1), impl(IMPL_AUTO), flops(0), bytes(0) { label[0] = 0; }
 };
 
 }  // namespace dmm

@@ -151,8 +151,10 @@ struct Bw1Args {
 };
 bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype);
 hipError_t launch_bw1(const Bw1Args& g, int dtype, hipStream_t st);
-hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st);
-hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st);
+hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st, int impl = IMPL_AUTO);
+hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int impl = IMPL_AUTO);
+int igemm_pick(const ConvArgs& a, int dtype, int epi, bool mfma);   // the family (enum Impl) that would run the launch now
+int wgrad_pick(const WgradArgs& a, int dtype, bool mfma);
 void thin_set_enabled(bool on);  // thin.hip
 void conv3_set_enabled(bool on);  // conv3.hip
 void wg3_set_enabled(bool on);    // wg3.hip

@@ -12,6 +12,8 @@
 
 namespace dmm {
 
+thread_local LaunchCtl g_ctl;  // see common.h
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void convert_input_kernel(ConvertArgs a) {

@@ -205,7 +205,7 @@ void thin_set_enabled(bool on) { g_no_thin = !on; }
 
 // Returns hipErrorNotSupported when the layer is not eligible.
 hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t st) {
-  if (g_no_thin || dtype == DT_F32 || epi != EPI_LOGITS || c.nseg != 1) return hipErrorNotSupported;
+  if (!family_on(!g_no_thin, IMPL_THIN) || dtype == DT_F32 || epi != EPI_LOGITS || c.nseg != 1) return hipErrorNotSupported;
   const Seg& sg = c.seg[0];
   if (sg.mode != G_PLAIN || sg.istride != 1 || sg.Hs != c.Ho || sg.Ws != c.Wo || c.ostride != 1 || c.py != 0 || c.px != 0 ||
       c.Hout != c.Ho || c.Wout != c.Wo)
@@ -233,6 +233,7 @@ hipError_t launch_thin_logits(const ConvArgs& c, int dtype, int epi, hipStream_t
   else if (R == 2 && c.N == 1) kern = bf ? thin_logits_kernel<bf16, 2, 1> : thin_logits_kernel<f16, 2, 1>;
   else if (R == 2 && c.N == 2) kern = bf ? thin_logits_kernel<bf16, 2, 2> : thin_logits_kernel<f16, 2, 2>;
   if (kern == nullptr) return hipErrorNotSupported;
+  if (g_ctl.dry) return hipSuccess;
   a.R = R;
   const int wout = TH_PX - 2 * R;
   a.nxs = (a.W + wout - 1) / wout;

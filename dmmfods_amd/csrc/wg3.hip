@@ -178,11 +178,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void wg3_kernel(const Wg3Args g) {
 static bool g_wg3 = getenv("DMM_NO_WG3") == nullptr;
 void wg3_set_enabled(bool on) { g_wg3 = on; }
 
-static thread_local bool g_wg3_dry = false;
-
 template <typename T, int PQ>
 static hipError_t launch_wg3_t(const Wg3Args& g, int nwg, hipStream_t st) {
-  if (g_wg3_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   auto kern = wg3_kernel<T, PQ>;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), W3_LDS, st, g);
   return hipGetLastError();
@@ -191,7 +189,7 @@ static hipError_t launch_wg3_t(const Wg3Args& g, int nwg, hipStream_t st) {
 // Returns hipErrorNotSupported unless this is the transposed-form weight gradient of a 128 -> 32 channel 3x3 convolution in a
 // 16-bit storage type.
 hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
-  if (!g_wg3 || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
+  if (!family_on(g_wg3, IMPL_WG3) || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
   const Seg& q = a.seg[0];
   const Seg& p = a.dy;
   if (q.mode != G_PLAIN || q.istride != 1 || q.ntaps != 9 || q.C != W3_CY || q.Cpad != W3_CY || q.Hs != a.Ho || q.Ws != a.Wo || q.scale != nullptr)
@@ -211,7 +209,7 @@ hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
   g.tiles_x = (a.Wo + W3_TW - 1) / W3_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
   // time ~ tiles/nwg * t_tile + nwg * (147 KB of fp32 atomics at the chip-wide atomic rate): minimum at nwg ~ sqrt(14 * tiles)
-  if (g_wg3_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   int nwg = (int)std::lround(std::sqrt(14.0 * g.ntiles));
@@ -224,9 +222,10 @@ hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
 }
 
 bool wg3_handles(const WgradArgs& a, int dtype) {
-  g_wg3_dry = true;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
   const hipError_t e = launch_wg3(a, dtype, nullptr);
-  g_wg3_dry = false;
+  g_ctl = keep;
   return e == hipSuccess;
 }
 

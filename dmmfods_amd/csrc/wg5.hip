@@ -219,7 +219,6 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
 static bool g_wg5 = getenv("DMM_NO_WG5") == nullptr;
 void wg5_set_enabled(bool on) { g_wg5 = on; }
 
-static thread_local bool g_wg5_dry = false;
 
 template <typename T, int TR, int STR, int PA>
 static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
@@ -234,7 +233,7 @@ static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
 // (b) 49 taps at stride 2 over the raw input, the 64 channels an output gradient (plain or with the deferred correction): the
 // stem's 7x7 convolution, normal form.  Returns hipErrorNotSupported otherwise.
 hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
-  if (!g_wg5 || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
+  if (!family_on(g_wg5, IMPL_WG5) || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
   const Seg& q = a.seg[0];
   const Seg& p = a.dy;
   const bool stem = q.ntaps == 49;
@@ -253,7 +252,7 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
     if (dy < -tr || dy > tr || dx < -tr || dx > tr || seen[(dy + tr) * (2 * tr + 1) + dx + tr]) return hipErrorNotSupported;
     seen[(dy + tr) * (2 * tr + 1) + dx + tr] = true;
   }
-  if (g_wg5_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   Wg5Args g;
   g.w = a;
   g.tiles_y = (a.Ho + W5_TH - 1) / W5_TH;
@@ -273,9 +272,10 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
 }
 
 bool wg5_handles(const WgradArgs& a, int dtype) {
-  g_wg5_dry = true;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
   const hipError_t e = launch_wg5(a, dtype, nullptr);
-  g_wg5_dry = false;
+  g_ctl = keep;
   return e == hipSuccess;
 }
 

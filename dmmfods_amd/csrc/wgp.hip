@@ -239,7 +239,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
 static bool g_wgp = getenv("DMM_NO_WGP") == nullptr;
 void wgp_set_enabled(bool on) { g_wgp = on; }
 
-static thread_local bool g_wgp_dry = false;
 
 template <typename T, int NTAP, int NJ, int PQ>
 static hipError_t launch_wgp_t(const WgpArgs& g, int nwg, hipStream_t st) {
@@ -266,11 +265,11 @@ static hipError_t launch_wgp_type(const WgpArgs& g, int ntap, int nj, int pq, in
 // the input a multiple of 128 channels and the output a multiple of 64.  Returns hipErrorNotSupported otherwise.  A second
 // (8-channel raw-input) segment is NOT covered: the caller runs it through the generic kernel (see launch_wgrad).
 hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
-  if (!g_wgp || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2) return hipErrorNotSupported;
+  if (!family_on(g_wgp, IMPL_WGP) || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2) return hipErrorNotSupported;
   const Seg& x = a.seg[0];
   const Seg& y = a.dy;
   static const bool trace = getenv("DMM_WGP_TRACE") != nullptr;
-  if (trace && !g_wgp_dry)
+  if (trace && !g_ctl.dry)
     fprintf(stderr, "wgp? nseg %d x: mode %d istride %d Hs %d Ws %d (Ho %d Wo %d) scale %d C %d Cpad %d ntaps %d | y: mode %d ntaps %d istride %d Hs %d Ws %d C %d | N %d Npad %d\n",
             a.nseg, x.mode, x.istride, x.Hs, x.Ws, a.Ho, a.Wo, x.scale != nullptr, x.C, x.Cpad, x.ntaps, y.mode, y.ntaps, y.istride, y.Hs, y.Ws, y.C, a.N, a.Npad);
   if (x.mode != G_PLAIN || x.istride != 1 || x.Hs != a.Ho || x.Ws != a.Wo || x.scale == nullptr || x.C % WP_CA || x.Cpad != x.C) return hipErrorNotSupported;
@@ -295,7 +294,7 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   if (py < 0 || px < 0 || py >= y.istride || px >= y.istride) return hipErrorNotSupported;
   const int ntap = x.ntaps;
   const int nj = (ntap == 2 && a.N % 128 == 0) ? 4 : 2;
-  if (g_wgp_dry) return hipSuccess;
+  if (g_ctl.dry) return hipSuccess;
   WgpArgs g;
   g.w = a;
   g.dymin = dymin; g.dxmin = dxmin;
@@ -320,9 +319,10 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
 }
 
 bool wgp_handles(const WgradArgs& a, int dtype) {
-  g_wgp_dry = true;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
   const hipError_t e = launch_wgp(a, dtype, nullptr);
-  g_wgp_dry = false;
+  g_ctl = keep;
   return e == hipSuccess;
 }
 

@@ -431,17 +431,39 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st);  // wgp.hi
 hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st);  // wg5.hip
 
 // Fills rows_per_split / kgroups (if zero) and launches.
-hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st) {
+// Which family launch_wgrad(..., IMPL_AUTO) would run right now (nothing is launched).
+int wgrad_pick(const WgradArgs& a, int dtype, bool mfma) {
+  if (!mfma || a.M <= 0) return IMPL_GENERIC;
+  const LaunchCtl keep = g_ctl;
+  g_ctl.dry = true;
+  g_ctl.impl = IMPL_AUTO;
+  int took = IMPL_GENERIC;
+  if (launch_wg3(a, dtype, nullptr) == hipSuccess) took = IMPL_WG3;
+  else if (launch_wg5(a, dtype, nullptr) == hipSuccess) took = IMPL_WG5;
+  else if (launch_wgp(a, dtype, nullptr) == hipSuccess) took = IMPL_WGP;
+  g_ctl = keep;
+  return took;
+}
+
+struct CtlScope {  // the family a plan recorded is the only one allowed to take the launch while this is alive
+  LaunchCtl keep;
+  explicit CtlScope(int impl) : keep(g_ctl) { g_ctl.dry = false; g_ctl.impl = impl; }
+  ~CtlScope() { g_ctl = keep; }
+};
+
+hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int impl) {
   if (a.M <= 0) return hipSuccess;
-  if (mfma) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
+  const CtlScope scope(impl);
+  const bool special = mfma && impl != IMPL_GENERIC;
+  if (special) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
     const hipError_t e = launch_wg3(a, dtype, st);
     if (e != hipErrorNotSupported) return e;
   }
-  if (mfma) {  // the head's 5x5 convolution onto 3 classes: persistent tiles, the 25 x 8 (tap, class) columns as per-lane addresses
+  if (special) {  // the head's 5x5 convolution onto 3 classes: persistent tiles, the 25 x 8 (tap, class) columns as per-lane addresses
     const hipError_t e = launch_wg5(a, dtype, st);
     if (e != hipErrorNotSupported) return e;
   }
-  if (mfma) {  // parity-phase convolutions (ConvTranspose stages, the head's 3x3 over the upsampled map): all taps of a phase per tile
+  if (special) {  // parity-phase convolutions (ConvTranspose stages, the head's 3x3 over the upsampled map): all taps of a phase per tile
     const hipError_t e = launch_wgp(a, dtype, st);
     if (e == hipSuccess) {
       if (a.nseg == 1) return e;

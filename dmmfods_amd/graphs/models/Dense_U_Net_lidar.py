@@ -72,7 +72,14 @@ class _Plan:
         _lib.check(L.dmm_plan_create(C.byref(desc), C.byref(self.handle)))
         nbytes = L.dmm_plan_workspace_bytes(self.handle)
         dev = model._param_arena.device
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # DMM_GUARD_MB=n (tests): n MiB of a known byte pattern on either side of the workspace; check_guards() tells whether any
+        # kernel wrote outside what the plan sized
+        self._guard = (int(os.environ.get("DMM_GUARD_MB", "0")) << 20)
+        self._raw = torch.empty(nbytes + 2 * self._guard, dtype=torch.uint8, device=dev)
+        if self._guard:
+            self._raw[:self._guard].fill_(0xA5)
+            self._raw[self._guard + nbytes:].fill_(0xA5)
+        self.workspace = self._raw[self._guard:self._guard + nbytes]
         nc = int(model.num_classes)
         self.metrics = torch.zeros(2 * nc + batch * 2 * nc, dtype=torch.float64, device=dev)
         self.flops_forward = L.dmm_plan_forward_flops(self.handle)
@@ -85,6 +92,13 @@ class _Plan:
             off, cnt = C.c_int64(), C.c_int64()
             _lib.check(L.dmm_plan_grad_bucket(self.handle, i, C.byref(off), C.byref(cnt)))
             self.grad_buckets.append((off.value, cnt.value))
+
+    def check_guards(self):
+        """True when the guard bands around the workspace (DMM_GUARD_MB) still hold their pattern."""
+        if not self._guard:
+            raise RuntimeError("no guard bands: set DMM_GUARD_MB before the plan is created")
+        g = self._guard
+        return bool((self._raw[:g] == 0xA5).all()) and bool((self._raw[g + self.workspace.numel():] == 0xA5).all())
 
     def __del__(self):
         try:

@@ -52,6 +52,8 @@ class GradAllReduce:
             return []
         model = self._src
         arena = self._arena()
+        if not hasattr(model, "grad_buckets"):   # a bare arena tensor: no plan, no readiness events - plain asynchronous buckets
+            return self.all_reduce(async_op=True)
         ranges = model.grad_buckets()
         self.last_ranges = ranges
         works = []

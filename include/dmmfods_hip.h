@@ -68,13 +68,16 @@ typedef struct dmm_plan dmm_plan;
 
 const char* dmm_last_error(void);
 int dmm_version(void);
-/* Kernel selection switches for tests and A/B timing: "thin_logits" (1 = gather-once kernel for the heat-map head's last
- * convolution, 0 = generic kernels), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the data-gradient
- * chain, 0 = one stream), "conv3" / "wg3" / "wgp" / "wg5" / "cvp" / "bw1" (1 = the LDS halo-tile kernels for the multi-tap convolutions / for the growth
- * convolution's weight gradient / for the weight gradients of the parity-phase convolutions / of the 5x5 head convolution / the ConvTranspose kernels / the fused backward of the 1x1 bottleneck convolutions, decided when a
- * plan is created; 0 = generic kernels), "grad_bucket_mb" (size of the data-parallel gradient buckets of plans created afterwards).
- * Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32 summation
- * order. */
+/* Kernel selection switches for tests and A/B timing: "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the
+ * data-gradient chain, 0 = one stream; read at every call), and the kernel families "thin_logits" (gather-once kernel for the
+ * heat-map head's last convolution), "conv3" (LDS halo-tile kernels of the multi-tap convolutions), "wg3" (the growth convolution's
+ * weight gradient), "wgp" (weight gradients of the parity-phase convolutions), "wg5" (of the 5x5 head / 7x7 stem convolutions),
+ * "cvp" (the ConvTranspose kernels), "bw1" (fused backward of the 1x1 bottleneck convolutions): 1 = on, 0 = generic kernels.
+ * A plan chooses the family of each of its launches ONCE, in dmm_plan_bind, from the switches of that moment, and keeps it
+ * (labels reported by dmm_plan_profile_op name the kernels that really run): toggle a switch BEFORE binding a plan.  The
+ * single-kernel entry points below read the switches at every call.  "grad_bucket_mb": size of the data-parallel gradient
+ * buckets of plans created afterwards.  Returns DMM_ERR_INVALID for an unknown name.  Results are identical up to the fp32
+ * summation order. */
 int dmm_set_option(const char* name, int value);
 
 /* Plan construction needs no GPU: it derives the layer table, the state_dict layout and the workspace size. */
@@ -175,6 +178,25 @@ int dmm_conv_wgrad(const dmm_conv_desc* d, const void* x, const void* dy, const 
  * shift, mean, invstd. */
 int dmm_conv_dgrad(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
                    void* gx, double* red, void* scratch, void* stream);
+
+
+/* The same two gradients as the plan's launches see them (autograd of torch.nn.functional.conv2d behind the reference's
+ * BatchNorm2d + ReLU, graphs/models/Dense_U_Net_lidar.py:85-92 via torchvision _DenseLayer):
+ *   - the incoming gradient may carry the deferred BatchNorm-backward correction of the layer behind it:
+ *     dy_eff = dy + q[c] + r[c] * yfwd[.., c]  (yfwd: T NHWC forward output of this convolution; q, r: Cout floats; all NULL = none);
+ *   - transposed_form != 0: the weight gradient with the taps on the gradient side, the form the plan uses for thin outputs
+ *     (the dense layers' 3x3 growth convolution: wg3.hip in 16-bit storage);
+ *   - accumulate != 0: gx += instead of gx =. */
+int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, const float* scale, const float* shift, const void* yfwd,
+                      const float* q, const float* r, int transposed_form, float* dw, void* scratch, void* stream);
+int dmm_conv_dgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
+                      const void* yfwd, const float* q, const float* r, void* gx, int accumulate, double* red, void* scratch,
+                      void* stream);
+/* Data gradient AND weight gradient of a 1x1 bottleneck convolution in one pass (bw1.hip; 16-bit storage, Cout == 128,
+ * Cin % 32 == 0; DMM_ERR_INVALID otherwise): the two results of dmm_conv_dgrad_ex and dmm_conv_wgrad_ex on the same operands. */
+int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale,
+                               const float* shift, const void* yfwd, const float* q, const float* r, void* gx, int accumulate,
+                               float* dw, double* red, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

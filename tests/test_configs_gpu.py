@@ -97,10 +97,7 @@ def test_baseline_architectures_against_reference_fixture(case, golden_dir):
         assert err < max(2e-3, 3 * noise), (err, noise)
 
 
-def test_full_size_c2_batch4_step_properties():
-    """BASELINE configs[1] exactly (d121 early fusion, batch 4, 1280x1920, fp16 storage): size-independent properties.
-    (a) the fused loss equals BCE computed by torch on the returned logits; (b) metric counts equal torch's on those
-    logits; (c) every parameter tensor receives a finite, non-zero gradient; (d) a second identical step reproduces the loss."""
+def _c2_full_size(monkeypatch=None):
     from oracle import restatement as R
     arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
     model = _model(arch, "fp16").to(DEV).train()
@@ -109,21 +106,36 @@ def test_full_size_c2_batch4_step_properties():
     rgb = torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) * 255
     lidar = torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) * 255 * (torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) > 0.9)
     tgt = (torch.rand(B, 3, 1280, 1920, device=DEV, generator=gen) > 0.9).float()
+    return model, rgb, lidar, tgt
+
+
+def _host_bce_sums(logits, tgt):
+    """Per-class sums of BCE-with-logits in fp64 on the HOST (numpy): independent of every GPU reduction."""
+    x = logits.detach().cpu().double().numpy()
+    t = tgt.detach().cpu().double().numpy()
+    l = np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))
+    return torch.from_numpy(l.sum(axis=(0, 2, 3)))
+
+
+def test_full_size_c2_batch4_step_properties(monkeypatch):
+    """BASELINE configs[1] exactly (d121 early fusion, batch 4, 1280x1920, fp16 storage): size-independent properties.
+    (a) the fused loss sums equal BCE summed in fp64 ON THE HOST from the returned logits (an independent third reference: round 2
+    saw torch's one-step GPU reduction disagree with the kernel on one class, see test_torch_gpu_reduction_... below);
+    (b) metric counts equal torch's on those logits; (c) every parameter tensor receives a finite, non-zero gradient;
+    (d) a second identical step reproduces the loss; (e) nothing wrote outside the plan's workspace (guard bands)."""
+    monkeypatch.setenv("DMM_GUARD_MB", "8")
+    model, rgb, lidar, tgt = _c2_full_size()
+    B = 4
+    guard_before = model.grad_arena.new_full((1 << 20,), 7.0)          # a neighbouring torch allocation the product never sees
     with torch.no_grad():
         logits = model(rgb, lidar)
     met = model.loss_backward(tgt)
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all()
-    # per-sample sums first, then over the batch: torch's one-step reduction over dims (0, 2, 3) of a 4 x 3 x 1280 x 1920 tensor has
-    # returned a wrong value for ONE class on this ROCm build in two runs (the product's number equalled every recomputation);
-    # both forms are evaluated and must agree, so a repeat of that shows up as torch's, not as the kernel's
-    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt, reduction="none").double()
-    ref_loss = bce.sum(dim=(2, 3)).sum(dim=0)
-    one_step = bce.sum(dim=(0, 2, 3))
-    if _rel(one_step, ref_loss) > 1e-9:
-        print(f"torch reduction disagreement: one-step {one_step.tolist()} vs two-step {ref_loss.tolist()}")
-    del bce
-    assert _rel(met["loss_per_class"], ref_loss) < 1e-5
+    host = _host_bce_sums(logits, tgt)
+    assert _rel(met["loss_per_class"], host) < 1e-6, (met["loss_per_class"].tolist(), host.tolist())
+    assert model._last[0].check_guards(), "a kernel wrote outside the plan's workspace"
+    assert bool((guard_before == 7.0).all())
     pred, gt = logits >= 0.7, tgt >= 0.7
     inter, union = (pred & gt).sum(dim=(2, 3)).double(), (pred | gt).sum(dim=(2, 3)).double()
     assert torch.equal(met["intersection"].cpu(), inter.cpu()) and torch.equal(met["union"].cpu(), union.cpu())
@@ -140,6 +152,31 @@ def test_full_size_c2_batch4_step_properties():
         model(rgb, lidar)
     met2 = model.loss_backward(tgt)
     assert _rel(met2["loss_per_class"], loss1) < 1e-6
+    assert model._last[0].check_guards()
+
+
+@pytest.mark.xfail(strict=False, reason="round 2, gpurun_out/cvp_model.log: torch's one-step GPU reduction sum(dim=(0,2,3)) over the "
+                                        "4x3x1280x1920 fp64 BCE tensor returned 3 874 303 for class 1 where the kernel, torch's two-step "
+                                        "reduction and (this round) the host fp64 sum give 3 919 912; recorded here instead of printed")
+def test_torch_gpu_reduction_agrees_with_host_on_the_c2_loss_tensor():
+    """Settles who was wrong in round 2's full-size loss mismatch: the three GPU-side candidates (the product's fused loss sums,
+    torch one-step, torch two-step) against the host fp64 sum of the same tensor.  The product is asserted in the test above; this
+    one fails (xfail) exactly when torch's one-step reduction is the outlier and shows all four numbers."""
+    model, rgb, lidar, tgt = _c2_full_size()
+    with torch.no_grad():
+        logits = model(rgb, lidar)
+    met = model.loss_backward(tgt)
+    torch.cuda.synchronize()
+    host = _host_bce_sums(logits, tgt)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt, reduction="none").double()
+    two_step = bce.sum(dim=(2, 3)).sum(dim=0)
+    one_step = bce.sum(dim=(0, 2, 3))
+    digest = float(bce.view(-1)[:: 9973].sum())
+    msg = (f"kernel {met['loss_per_class'].tolist()} host {host.tolist()} torch two-step {two_step.tolist()} one-step {one_step.tolist()} "
+           f"bce digest {digest!r}")
+    print(msg)
+    assert _rel(two_step, host) < 1e-9, msg
+    assert _rel(one_step, host) < 1e-9, msg
 
 
 def test_fp16_training_trajectory_tracks_fp32_oracle():
@@ -207,11 +244,13 @@ def test_bf16_storage_d201_mid3_against_oracle_emulation():
         den += float(gb[k].pow(2).sum())
     e_g, y_g = (num / den) ** 0.5, (ynum / den) ** 0.5
     print(f"bf16 d201 mid3: logits {e_log:.3e} (emulation vs fp64 {y_log:.3e}), loss {e_loss:.3e}, grads rel L2 {e_g:.3e} (emulation vs fp64 {y_g:.3e})")
-    # bf16 keeps 8 significant bits: the storage rounding itself moves the logits by y_log; the HIP path may differ from the
-    # emulation by as much again (different summation order meeting the same rounding points)
-    assert e_log < max(5e-2, 2 * y_log), (e_log, y_log)
-    assert e_loss < 2e-2, e_loss
-    assert e_g < max(0.15, 2 * y_g), (e_g, y_g)
+    # bf16 keeps 8 significant bits and this net runs 200 BatchNorms in series: the storage rounding itself moves the emulation
+    # y_log / y_g away from fp64.  Two evaluations that meet the same rounding points in a different summation order sit about
+    # that far apart; the HIP path must be CLOSER to the emulation than the emulation is to fp64 (measured 0.74x / 0.81x of the
+    # yardsticks in round 2).  The per-kernel and layer-depth bf16 bounds are in tests/test_timed_kernels_gpu.py.
+    assert e_log < y_log, (e_log, y_log)
+    assert e_loss < 5e-3, e_loss          # measured 7.8e-4
+    assert e_g < y_g, (e_g, y_g)
 
 
 @pytest.mark.parametrize("variant,H,W", [("early", 32, 32), ("mid3", 32, 96), ("no", 96, 32), ("mid2", 160, 64), ("mid4", 224, 96),

@@ -289,9 +289,11 @@ def test_thin_logits_kernel_matches_generic_kernels():
         out = {}
         for on in (1, 0):
             _lib.check(_lib.lib().dmm_set_option(b"thin_logits", on))
+            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 out[on] = model(rgb, lidar).clone()
         _lib.check(_lib.lib().dmm_set_option(b"thin_logits", 1))
+        model._plans.clear()
         scale = float(out[0].abs().max())
         assert scale > 0 and torch.isfinite(out[1]).all()
         assert float((out[1] - out[0]).abs().max()) <= 1e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
@@ -380,6 +382,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"conv3", on))
+            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 logits = model(rgb, lidar).clone()
             met = model.loss_backward(tgt)
@@ -388,6 +391,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
             model._tracked_arena.zero_()
     finally:
         _lib.check(L.dmm_set_option(b"conv3", 1))
+        model._plans.clear()
     assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][2]).all()
     tol = 1e-2 if dtype == "fp16" else 1.6e-2   # measured 3.1e-3 / 0 on the logits, 4.9e-3 / 3e-4 on the gradients
     e_log = _rel(out[1][0], out[0][0])
@@ -403,6 +407,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wg3", on))
+            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
@@ -410,6 +415,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
             grads[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if k.endswith("conv2.weight")}
     finally:
         _lib.check(L.dmm_set_option(b"wg3", 1))
+        model._plans.clear()
     worst = max(((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm()).item() for k in grads[1])
     print(f"   wg3 vs generic on identical operands: worst conv2.weight gradient rel L2 {worst:.3e}")
     assert len(grads[1]) >= 9 and worst < 2e-4
@@ -436,22 +442,23 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wgp", on))
+            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
             torch.cuda.synchronize()
             grads[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters()
                          if "Transposed_Convolution_" in k and k.endswith(".weight") and "Sequence" not in k or k.endswith("refine0.weight")}
+            if on:   # the plan labels its launches by the kernel that runs them: the phases with 2 or 4 taps must be on wgp
+                plan = model._last[0]
+                labels = []
+                for i in range(L.dmm_plan_profile_num_ops(plan.handle, 1)):
+                    label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+                    L.dmm_plan_profile_op(plan.handle, 1, i, C.byref(label), C.byref(fl), C.byref(by))
+                    labels.append((label.value or b"").decode())
     finally:
         _lib.check(L.dmm_set_option(b"wgp", 1))
-    # the plan labels its launches by the kernel that runs them: the phases with 2 or 4 taps must be on wgp
-    plan = model._last[0]
-    n = L.dmm_plan_profile_num_ops(plan.handle, 1)
-    labels = []
-    for i in range(n):
-        label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
-        L.dmm_plan_profile_op(plan.handle, 1, i, C.byref(label), C.byref(fl), C.byref(by))
-        labels.append((label.value or b"").decode())
+        model._plans.clear()
     on_wgp = [x for x in labels if x.startswith("wgp.")]
     assert len(on_wgp) >= 3 * 4, on_wgp                       # 3 multi-tap phases x 4 ConvTranspose stages (+ the head's 4 if eligible)
     assert len(grads[1]) == 5
@@ -465,6 +472,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wg5", on))
+            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
@@ -472,6 +480,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
             g5[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if k in names}
     finally:
         _lib.check(L.dmm_set_option(b"wg5", 1))
+        model._plans.clear()
     assert sorted(x.split("/")[1] for x in labels if x.startswith("wg5.")) == ["f.conv0", "h.refine1"], [x for x in labels if x.startswith("wg5.")]
     for k in names:
         e5 = ((g5[1][k] - g5[0][k]).norm() / g5[0][k].norm()).item()

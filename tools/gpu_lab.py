@@ -103,6 +103,85 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
     return not bad
 
 
+def _eff_setup(g, dt, B, Cout, Ho, Wo, with_q):
+    """Incoming gradient of a convolution output as the plan's launches see it: raw gradient dy, and optionally the deferred
+    BatchNorm-backward correction q + r * yfwd of the layer behind it (yfwd = that layer's input = this convolution's output)."""
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    dyq = dy.to(dt).float()
+    if not with_q:
+        return dy, dyq, None, None, None, dyq
+    yf = torch.randn(B, Cout, Ho, Wo, generator=g) * 1.5
+    yfq = yf.to(dt).float()
+    q = torch.randn(Cout, generator=g) * 0.3
+    r = torch.randn(Cout, generator=g) * 0.2
+    eff = dyq + q.view(1, -1, 1, 1) + r.view(1, -1, 1, 1) * yfq
+    return dy, dyq, yf, q, r, eff
+
+
+def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with_q=1, acc=0, what="dgrad", seed=0):
+    """The backward launches of the timed configuration, each through its C-ABI entry point against autograd of
+    torch.nn.functional on the CPU (fp32 reference of the same op, 16-bit-rounded operands):
+      what = "fused":  dmm_conv1x1_backward_fused (bw1.hip): data + weight gradient of a 1x1 bottleneck convolution
+             "dgrad":  dmm_conv_dgrad_ex with the effective-gradient prologue (conv3.hip PRO=2 for the dense 3x3)
+             "wgradT": dmm_conv_wgrad_ex in the transposed form (wg3.hip for the dense 3x3)
+             "wgrad":  dmm_conv_wgrad_ex, normal form, with the effective-gradient prologue (wgp.hip for ConvTranspose phases)"""
+    g = torch.Generator().manual_seed(seed)
+    dt = {1: torch.float16, 2: torch.bfloat16}[dtype]
+    x = (torch.randn(B, Cin, H, W, generator=g) * 2 + 0.5)
+    scale = torch.rand(Cin, generator=g) + 0.5
+    shift = torch.randn(Cin, generator=g) * 0.5
+    mean = torch.randn(Cin, generator=g)
+    invstd = torch.rand(Cin, generator=g) + 0.5
+    wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, R, S)
+    w = torch.randn(wshape, generator=g) / (Cin * R * S) ** 0.5
+    xq = x.to(dt).float()
+    z = xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    a = F.relu(z).requires_grad_(True)
+    wq = w.clone().requires_grad_(True)
+    y = F.conv_transpose2d(a, wq, stride=2, padding=1, output_padding=1) if transposed else F.conv2d(a, wq, padding=pad)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy, dyq, yf, q, r, eff = _eff_setup(g, dt, B, Cout, Ho, Wo, with_q)
+    (y * eff).sum().backward()
+    dz = a.grad * (z > 0)
+    gold = (torch.randn(B, Cin, H, W, generator=g)).to(dt) if acc else None
+    gx_ref = dz * scale.view(1, -1, 1, 1) + (gold.float() if acc else 0.0)
+    xhat = (xq.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    d = _lib.ConvDesc(dtype=dtype, use_mfma=1, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, stride=2 if transposed else 1, pad=pad,
+                      transposed=transposed, mode=0, bn_relu=1)
+    scratch = torch.zeros(L.dmm_conv_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+    xd, dyd = nhwc(x, dt).to(DEV), nhwc(dy, dt).to(DEV)
+    yfd = nhwc(yf, dt).to(DEV) if with_q else None
+    qd, rd = (q.to(DEV), r.to(DEV)) if with_q else (None, None)
+    wd, sd, hd = w.to(DEV), scale.to(DEV), torch.cat([shift, mean, invstd]).to(DEV)
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    st = _lib.stream_ptr()
+    res = {}
+    gxd = nhwc(gold.float(), dt).to(DEV) if acc else torch.full((B, H, W, Cin), float("nan"), dtype=dt, device=DEV)
+    red = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    dwd = torch.full(wshape, float("nan"), device=DEV)
+    if what == "fused":
+        _lib.check(L.dmm_conv1x1_backward_fused(C.byref(d), xd.data_ptr(), dyd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(),
+                                                ptr(yfd), ptr(qd), ptr(rd), gxd.data_ptr(), acc, dwd.data_ptr(), red.data_ptr(),
+                                                scratch.data_ptr(), st))
+    elif what == "dgrad":
+        _lib.check(L.dmm_conv_dgrad_ex(C.byref(d), xd.data_ptr(), dyd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(),
+                                       ptr(yfd), ptr(qd), ptr(rd), gxd.data_ptr(), acc, red.data_ptr(), scratch.data_ptr(), st))
+    else:
+        _lib.check(L.dmm_conv_wgrad_ex(C.byref(d), xd.data_ptr(), dyd.data_ptr(), sd.data_ptr(), hd.data_ptr(), ptr(yfd), ptr(qd), ptr(rd),
+                                       1 if what == "wgradT" else 0, dwd.data_ptr(), scratch.data_ptr(), st))
+    torch.cuda.synchronize()
+    if what in ("fused", "dgrad"):
+        res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref)
+        res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)))
+        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xhat).sum(dim=(0, 2, 3)))
+    if what != "dgrad":
+        res["wgrad"] = relerr(dwd.cpu(), wq.grad)
+    tol = {1: 3e-3, 2: 2.5e-2}[dtype]
+    bad = [k for k, v in res.items() if not (v < tol)]
+    print(f"{'FAIL' if bad else 'ok  '} {what:6s} {name:28s} dt={dtype} q={with_q} acc={acc} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
+    return not bad
+
+
 CASES = [
     # name, B,H,W,Cin,Cout,R,S,stride,pad, transposed, mode, bn
     ("1x1 72->32", 2, 12, 20, 72, 32, 1, 1, 1, 0, 0, 0, 1),
