@@ -298,10 +298,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
         }
       }
     }
-    // the next group's weights (issued one iteration ago) must have landed; this iteration's DMA stays in flight
-    if (grp + 2 < NGRP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // The next group's weights (issued one iteration ago) must have landed; this iteration's DMA stays in flight.  lgkmcnt(0): every
+    // fragment read of THIS group must have RETURNED before the barrier, because the first thing behind it is the DMA that refills
+    // the slot they read (WAR).  The data dependence of the MFMAs does not give that: hipcc sinks a group's last MFMAs - and the
+    // wait for their operands - below the barrier, and with the stem's small, L2-resident weights the refill can land (~250 cycles)
+    // before a queued ds_read has executed (seen as 0.1 % wrong outputs of the 7x7 stem convolution at 4 x 1280 x 1920, run to run
+    // different, never at parity-test sizes).  Wait and barrier are ONE asm statement so that nothing is scheduled between them.
+    if (grp + 2 < NGRP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if ((C3_DBG & 8) && acc[0][0] != 123.f) return;
   // all waves are past the last barrier: the images and the ring are dead, reuse them for staging

@@ -175,8 +175,9 @@ def test_torch_gpu_reduction_agrees_with_host_on_the_c2_loss_tensor():
     msg = (f"kernel {met['loss_per_class'].tolist()} host {host.tolist()} torch two-step {two_step.tolist()} one-step {one_step.tolist()} "
            f"bce digest {digest!r}")
     print(msg)
-    assert _rel(two_step, host) < 1e-9, msg
-    assert _rel(one_step, host) < 1e-9, msg
+    # torch evaluates BCE in fp32 per element before the fp64 sum; the host evaluates it in fp64: 1e-8 apart on 1e7-element sums
+    assert _rel(two_step, host) < 1e-7, msg
+    assert _rel(one_step, host) < 1e-7, msg
 
 
 def test_fp16_training_trajectory_tracks_fp32_oracle():

@@ -106,34 +106,37 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
 def _eff_setup(g, dt, B, Cout, Ho, Wo, with_q):
     """Incoming gradient of a convolution output as the plan's launches see it: raw gradient dy, and optionally the deferred
     BatchNorm-backward correction q + r * yfwd of the layer behind it (yfwd = that layer's input = this convolution's output)."""
-    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    kw = dict(generator=g, device=g.device)
+    dy = torch.randn(B, Cout, Ho, Wo, **kw)
     dyq = dy.to(dt).float()
     if not with_q:
         return dy, dyq, None, None, None, dyq
-    yf = torch.randn(B, Cout, Ho, Wo, generator=g) * 1.5
+    yf = torch.randn(B, Cout, Ho, Wo, **kw) * 1.5
     yfq = yf.to(dt).float()
-    q = torch.randn(Cout, generator=g) * 0.3
-    r = torch.randn(Cout, generator=g) * 0.2
+    q = torch.randn(Cout, **kw) * 0.3
+    r = torch.randn(Cout, **kw) * 0.2
     eff = dyq + q.view(1, -1, 1, 1) + r.view(1, -1, 1, 1) * yfq
     return dy, dyq, yf, q, r, eff
 
 
-def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with_q=1, acc=0, what="dgrad", seed=0):
+def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with_q=1, acc=0, what="dgrad", seed=0, ref_dev="cpu"):
     """The backward launches of the timed configuration, each through its C-ABI entry point against autograd of
     torch.nn.functional on the CPU (fp32 reference of the same op, 16-bit-rounded operands):
       what = "fused":  dmm_conv1x1_backward_fused (bw1.hip): data + weight gradient of a 1x1 bottleneck convolution
              "dgrad":  dmm_conv_dgrad_ex with the effective-gradient prologue (conv3.hip PRO=2 for the dense 3x3)
              "wgradT": dmm_conv_wgrad_ex in the transposed form (wg3.hip for the dense 3x3)
              "wgrad":  dmm_conv_wgrad_ex, normal form, with the effective-gradient prologue (wgp.hip for ConvTranspose phases)"""
-    g = torch.Generator().manual_seed(seed)
+    # ref_dev="cuda": the torch reference itself runs on the GPU (production sizes; fp32 autograd of the same op)
+    g = torch.Generator(device=ref_dev).manual_seed(seed)
     dt = {1: torch.float16, 2: torch.bfloat16}[dtype]
-    x = (torch.randn(B, Cin, H, W, generator=g) * 2 + 0.5)
-    scale = torch.rand(Cin, generator=g) + 0.5
-    shift = torch.randn(Cin, generator=g) * 0.5
-    mean = torch.randn(Cin, generator=g)
-    invstd = torch.rand(Cin, generator=g) + 0.5
+    kw = dict(generator=g, device=ref_dev)
+    x = (torch.randn(B, Cin, H, W, **kw) * 2 + 0.5)
+    scale = torch.rand(Cin, **kw) + 0.5
+    shift = torch.randn(Cin, **kw) * 0.5
+    mean = torch.randn(Cin, **kw)
+    invstd = torch.rand(Cin, **kw) + 0.5
     wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, R, S)
-    w = torch.randn(wshape, generator=g) / (Cin * R * S) ** 0.5
+    w = torch.randn(wshape, **kw) / (Cin * R * S) ** 0.5
     xq = x.to(dt).float()
     z = xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     a = F.relu(z).requires_grad_(True)
@@ -143,7 +146,7 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     dy, dyq, yf, q, r, eff = _eff_setup(g, dt, B, Cout, Ho, Wo, with_q)
     (y * eff).sum().backward()
     dz = a.grad * (z > 0)
-    gold = (torch.randn(B, Cin, H, W, generator=g)).to(dt) if acc else None
+    gold = (torch.randn(B, Cin, H, W, **kw)).to(dt) if acc else None
     gx_ref = dz * scale.view(1, -1, 1, 1) + (gold.float() if acc else 0.0)
     xhat = (xq.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
     d = _lib.ConvDesc(dtype=dtype, use_mfma=1, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, stride=2 if transposed else 1, pad=pad,
@@ -171,15 +174,52 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
                                        1 if what == "wgradT" else 0, dwd.data_ptr(), scratch.data_ptr(), st))
     torch.cuda.synchronize()
     if what in ("fused", "dgrad"):
-        res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref)
-        res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)))
-        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xhat).sum(dim=(0, 2, 3)))
+        res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref.cpu())
+        res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)).cpu())
+        res["red2"] = relerr(red[Cin:].cpu(), (dz.double() * xhat).sum(dim=(0, 2, 3)).cpu())
     if what != "dgrad":
-        res["wgrad"] = relerr(dwd.cpu(), wq.grad)
+        res["wgrad"] = relerr(dwd.cpu(), wq.grad.cpu())
     tol = {1: 3e-3, 2: 2.5e-2}[dtype]
     bad = [k for k, v in res.items() if not (v < tol)]
     print(f"{'FAIL' if bad else 'ok  '} {what:6s} {name:28s} dt={dtype} q={with_q} acc={acc} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
     return not bad
+
+
+def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn, transposed=0, reps=3):
+    """A forward convolution at a PRODUCTION size through the C ABI, several times on identical operands: against torch's GPU
+    convolution (fp32 on the same 16-bit-rounded operands) and run to run (bitwise).  Timing-dependent hazards of the LDS pipelines
+    (a refill landing before a queued fragment read has executed) only show with the chip full; parity-test shapes cannot see them."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    dt = {1: torch.float16, 2: torch.bfloat16}[dtype]
+    x = torch.randn(B, Cin, H, W, device=DEV, generator=g) * 2 + 0.5
+    scale = torch.rand(Cin, device=DEV, generator=g) + 0.5
+    shift = torch.randn(Cin, device=DEV, generator=g) * 0.5
+    wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, R, R)
+    w = torch.randn(wshape, device=DEV, generator=g) / (Cin * R * R) ** 0.5
+    xq = x.to(dt).float()
+    a = F.relu(xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dt).float() if bn else xq
+    wq = w.to(dt).float()
+    ref = F.conv_transpose2d(a, wq, stride=2, padding=1, output_padding=1) if transposed else F.conv2d(a, wq, stride=stride, padding=pad)
+    d = _lib.ConvDesc(dtype=dtype, use_mfma=1, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=R, stride=stride, pad=pad, transposed=transposed,
+                      mode=0, bn_relu=bn)
+    scratch = torch.zeros(L.dmm_conv_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    outs = []
+    for _ in range(reps):
+        yd = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), dtype=dt, device=DEV)
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+        _lib.check(L.dmm_conv_forward(C.byref(d), xd.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), yd.data_ptr(),
+                                      stats.data_ptr(), scratch.data_ptr(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(yd.permute(0, 3, 1, 2).float())
+    top = float(ref.abs().max())
+    tol = {1: 3e-3, 2: 2.5e-2}[dtype]
+    errs = [float((o - ref).abs().max()) / top for o in outs]
+    nbad = [int(((o - ref).abs() > tol * top).sum()) for o in outs]
+    ndiff = [int((o != outs[0]).sum()) for o in outs[1:]]
+    ok = max(errs) < tol and not any(ndiff)
+    print(f"{'ok  ' if ok else 'FAIL'} production {name:36s} dt={dtype} err " + " ".join(f"{e:.2e}" for e in errs) + f" bad {nbad} run-to-run differing {ndiff}", flush=True)
+    return ok
 
 
 CASES = [
