@@ -71,6 +71,8 @@ class Dense_U_Net_lidar_Agent:
             self.lr_scheduler = _StepLR(self.optimizer, o.lr_scheduler.every_n_epochs, o.lr_scheduler.gamma)
         self.current_epoch = self.current_train_iteration = self.current_val_iteration = 0
         self.best_val_iou = 0
+        # per-epoch averages as the reference logs them (A:301-307, A:392-398), kept for callers / tests: one dict per epoch
+        self.train_history, self.val_history = [], []
         self.cuda = torch.cuda.is_available()
         if not self.cuda:
             raise RuntimeError("dmmfods_amd computes on the GPU only (no CPU fallback)")
@@ -177,6 +179,8 @@ class Dense_U_Net_lidar_Agent:
             self.current_train_iteration += 1
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
+        self.train_history.append({"epoch": self.current_epoch, "loss": ep["loss"].mean(0).cpu(), "iou": ep["iou"].mean(0).cpu(),
+                                   "nans": ep["nans"].sum(0).cpu(), "acc": ep["acc"].mean(0).cpu()})
         self.logger.info("Training at Epoch-%d | Average Loss: %s | Average IoU: %s | Number of NaNs: %s | Average Accuracy: %s",
                          self.current_epoch, ep["loss"].mean(0).tolist(), ep["iou"].mean(0).tolist(), ep["nans"].sum(0).tolist(),
                          ep["acc"].mean(0).tolist())
@@ -196,6 +200,8 @@ class Dense_U_Net_lidar_Agent:
                 self._log(self.val_summary_writer, "Validation", m["loss_per_class"], acc_pc, iou_pc, self.current_val_iteration)
                 self.current_val_iteration += 1
         avg_iou = ep["iou"].mean(0).tolist()
+        self.val_history.append({"epoch": self.current_epoch, "loss": ep["loss"].mean(0).cpu(), "iou": ep["iou"].mean(0).cpu(),
+                                 "nans": ep["nans"].sum(0).cpu(), "acc": ep["acc"].mean(0).cpu()})
         self.logger.info("Validation at Epoch-%d | Average Loss: %s | Average IoU: %s | Number of NaNs: %s | Average Accuracy: %s",
                          self.current_epoch, ep["loss"].mean(0).tolist(), avg_iou, ep["nans"].sum(0).tolist(), ep["acc"].mean(0).tolist())
         return avg_iou

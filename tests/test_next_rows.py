@@ -195,3 +195,118 @@ def test_agent_trains_validates_and_resumes(tmp_path):
     torch.testing.assert_close(met["loss_per_class"].double(), unreduced.detach().double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
     assert torch.isfinite(g_auto).all() and float(g_auto.abs().max()) > 0
     assert ((m.grad_arena - g_auto).norm() / g_auto.norm()).item() < 1e-5
+
+
+def _reference_batch_block(iou):
+    """The reference agent's per-batch statements A:252-256 on an IoU table (instances x classes), replayed with numpy."""
+    import numpy as np
+    with np.errstate(invalid="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            pc = np.nanmean(iou, axis=0)
+    nans = np.isnan(iou).sum(axis=0)
+    return np.nan_to_num(pc, nan=0.0), nans
+
+
+@pytest.mark.gpu
+def test_agent_epochs_match_oracle_trainer(tmp_path, monkeypatch):
+    """SURVEY 8(f) row 2, numerically: Dense_U_Net_lidar_Agent.run() for two epochs over batched .pt files (the reference's on-disk
+    format, D:87-103) against oracle.Trainer driven over the same files in the same order with the reference agent's statements
+    (train_one_epoch A:215-307, validate A:309-398, best-checkpoint rule A:206-210): per-epoch loss / IoU / NaN-count / accuracy
+    averages, the best-checkpoint decision of every epoch, the weights after the run; then a checkpoint in the reference's dict
+    format (A:106-122) written from the ORACLE's state resumes in a fresh agent and a third epoch matches again.
+    The reference agent itself cannot be instantiated on the CPU container (.cuda() at A:54), and fixture G6's batch files are
+    16 x 24 images (below the network's 32-pixel granularity), so the files are generated here, 64 x 96.  fp32, a small
+    architecture through the factory hook (the reference agent hard-codes DenseNet-121, A:44; Adam on 121 layers of fp32 noise
+    would need bounds too loose to mean anything)."""
+    import numpy as np
+    from oracle import restatement as R
+    from dmmfods_amd.agents import Dense_U_Net_lidar_Agent as mod
+    from dmmfods_amd.graphs.models.Dense_U_Net_lidar import Dense_U_Net_lidar
+    cfg = _cfg(tmp_path)
+    _write_batches(cfg, nfiles=3, n=2)
+    cfg.agent.max_epoch = 2
+    tiny = dict(growth_rate=8, block_config=(2, 2, 2, 2), num_init_features=16)
+
+    def factory(pretrained=False, config=None, compute_dtype=None, **kw):
+        config.model.growth_rate, config.model.block_config, config.model.num_init_features = 8, (2, 2, 2, 2), 16
+        return Dense_U_Net_lidar(config, compute_dtype=compute_dtype)
+    monkeypatch.setattr(mod, "densenet121_u_lidar", factory)
+    agent = mod.Dense_U_Net_lidar_Agent(cfg, compute_dtype="fp32")
+    arch = R.Arch(**tiny, concat_before_block_num=cfg.model.concat_before_block_num, stream_2_in_channels=cfg.model.stream_2_in_channels)
+    state = R.make_state(arch, seed=99)
+    agent.model.load_state_dict(state)
+
+    # ---- the oracle, driven like the reference agent ----
+    P = R.make_state(arch, seed=99)
+    o = cfg.optimizer
+    tr = R.Trainer(arch, P, lr=o.learning_rate, betas=(o.beta1, o.beta2), eps=o.eps, iou_threshold=cfg.agent.iou_threshold)
+    from dmmfods_amd.datasets.WaymoData import WaymoDataset
+    files = {m: [torch.load(os.path.join(cfg.dir.data.root, f)) for f in WaymoDataset(m, cfg).files] for m in ("train", "val")}
+
+    def oracle_epoch(which):
+        rows = {k: [] for k in ("loss", "iou", "nans", "acc")}
+        for batch in files[which]:
+            rgb, lidar, tgt = batch[:, :3], batch[:, 3:4], batch[:, 4:]
+            out = tr.step(rgb, lidar, tgt) if which == "train" else tr.evaluate(rgb, lidar, tgt)
+            pc, nans = _reference_batch_block(out["iou"].numpy())
+            rows["loss"].append(out["loss_per_class"].numpy()); rows["iou"].append(pc); rows["nans"].append(nans)
+            rows["acc"].append(out["acc"].numpy())
+        return {k: (np.sum(v, axis=0) if k == "nans" else np.mean(v, axis=0)) for k, v in rows.items()}
+
+    def compare(hist, ref, tag):
+        np.testing.assert_allclose(hist["loss"].numpy(), ref["loss"], rtol=2e-3, err_msg=tag)
+        np.testing.assert_allclose(hist["iou"].numpy(), ref["iou"], atol=2e-3, err_msg=tag)
+        np.testing.assert_allclose(hist["acc"].numpy(), ref["acc"], atol=2e-3, err_msg=tag)
+        assert np.array_equal(hist["nans"].numpy().astype(np.int64), ref["nans"].astype(np.int64)), tag
+
+    ref_best, ref_decisions, ref_hist = 0.0, [], []
+    for epoch in range(2):
+        t, v = oracle_epoch("train"), oracle_epoch("val")
+        val_iou = float(np.sum(v["iou"]) / len(v["iou"]))          # A:206: sum(avg_val_iou_per_class) / len(...)
+        ref_decisions.append(val_iou > ref_best)
+        ref_best = max(ref_best, val_iou)
+        ref_hist.append((t, v))
+
+    # ---- the agent ----
+    saved = []
+    real_save = agent.save_checkpoint
+    monkeypatch.setattr(agent, "save_checkpoint", lambda filename="checkpoint.pth.tar", is_best=False: (saved.append(is_best), real_save(filename, is_best))[1])
+    agent.run()
+    assert len(agent.train_history) == 2 and len(agent.val_history) == 2
+    for e in range(2):
+        compare(agent.train_history[e], ref_hist[e][0], f"train epoch {e}")
+        compare(agent.val_history[e], ref_hist[e][1], f"val epoch {e}")
+    assert saved == ref_decisions, (saved, ref_decisions)
+    assert abs(float(agent.best_val_iou) - ref_best) < 2e-3
+    assert agent.current_train_iteration == 6 and agent.current_val_iteration == 6
+
+    def weight_error():
+        num = den = 0.0
+        for k, p in agent.model.named_parameters():
+            num += float((p.detach().cpu().double() - P[k].detach().double()).pow(2).sum())
+            den += float(P[k].detach().double().pow(2).sum())
+        return (num / den) ** 0.5
+    e6 = weight_error()
+    print(f"agent vs oracle after 2 epochs (6 Adam steps): weights rel L2 {e6:.3e}; best val IoU {float(agent.best_val_iou):.5f} vs {ref_best:.5f}; decisions {saved}")
+    assert e6 < 2e-3      # Adam steps are +-lr per element where the gradient is noise: 6 steps of 1e-3 on weights of O(0.1-1)
+
+    # ---- resume from a checkpoint in the reference's format, written from the ORACLE's state ----
+    k = cfg.agent.checkpoint
+    sd = {name: t.detach().clone() for name, t in P.items()}
+    ck = {k.epoch: 2, k.train_iteration: 6, k.val_iteration: 6, k.best_val_iou: ref_best, k.state_dict: sd, k.optimizer: tr.opt.state_dict()}
+    os.makedirs(cfg.dir.current_run.checkpoints, exist_ok=True)
+    torch.save(ck, os.path.join(cfg.dir.current_run.checkpoints, cfg.agent.best_checkpoint_name))
+    agent2 = mod.Dense_U_Net_lidar_Agent(cfg, torchvision_init=False, compute_dtype="fp32")
+    assert (agent2.current_epoch, agent2.current_train_iteration, agent2.current_val_iteration) == (2, 6, 6)
+    assert agent2.optimizer.step_count == 6
+    cfg.agent.max_epoch = 3
+    agent2.run()
+    t, v = oracle_epoch("train"), oracle_epoch("val")
+    compare(agent2.train_history[0], t, "resumed train epoch")
+    compare(agent2.val_history[0], v, "resumed val epoch")
+    agent = agent2
+    e9 = weight_error()
+    print(f"resumed from the oracle's checkpoint, third epoch: weights rel L2 {e9:.3e}")
+    assert e9 < 2e-3
