@@ -633,13 +633,20 @@ struct Builder {
       o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
       tag(o, ncls(o.impl == IMPL_WG3 ? "wg3" : (o.impl == IMPL_WG5 ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
           src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
-    } else
+    } else {
+    // The head's first convolution (two segments, four output-parity phases): the phase split exists for the upsampled decoder
+    // segment; the 8-channel raw-input segment is a plain 3x3 convolution over the full-resolution grid, whose weight gradient is ONE
+    // pass over the output gradient (wg5.hip) instead of four generic launches that each re-gather a quarter of it tap by tap.  Its
+    // result goes to phase 0's packed gradient (the phases' packed gradients are summed into the master weights by unpack).
+    const bool raw_once = c.nseg == 2 && c.phases.size() == 4 && c.shared_master && c.seg[1].C == 8 && c.seg[1].istride == 2 &&
+                          c.ostride == 2 && getenv("DMM_NO_RAW_ONCE") == nullptr;
+    const int wseg = raw_once ? 1 : c.nseg;
     for (auto& ph : c.phases) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;
       memset(&a, 0, sizeof(a));
-      a.nseg = c.nseg;
-      for (int s = 0; s < c.nseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], (s == 1 && !ph.taps1.empty()) ? ph.taps1 : ph.taps);
+      a.nseg = wseg;
+      for (int s = 0; s < wseg; ++s) fill_fwd_seg(a.seg[s], c.seg[s], (s == 1 && !ph.taps1.empty()) ? ph.taps1 : ph.taps);
       a.B = c.B; a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.B * c.Ho * c.Wo;
       fill_grad_seg(a.dy, c.obuf, c.och0, Nst, taps_conv(1, 1, 0), c.ostride);
       one_tap_seg(a.dy, ph.py, ph.px);
@@ -651,9 +658,30 @@ struct Builder {
         const double np = (double)c.phases.size();
         // reads: forward operand, output gradient and (for the deferred correction) the forward output; writes dW
         o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
-        tag(o, ncls(o.impl == IMPL_WGP ? "wgp" : (o.impl == IMPL_WG5 ? "wg5" : "wgrad"), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        tag(o, ncls(o.impl == IMPL_WGP ? "wgp" : (o.impl == IMPL_WG5 ? "wg5" : "wgrad"), pd.Npad, cb), short_name(c.wname),
+            conv_flops(c, c.phases.size()) * (raw_once ? (double)c.seg[0].Cw / c.Kin : 1.0),
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
+    }
+    if (raw_once) {
+      Op& o = push(OP_WGRAD);
+      WgradArgs& a = o.w;
+      memset(&a, 0, sizeof(a));
+      a.nseg = 1;
+      fill_fwd_seg(a.seg[0], c.seg[1], taps_conv(3, 3, 1));
+      a.seg[0].istride = 1;                                  // the row grid is the full-resolution output grid
+      a.B = c.B; a.Ho = ob.H; a.Wo = ob.W; a.M = c.B * ob.H * ob.W;
+      fill_grad_seg(a.dy, c.obuf, c.och0, Nst, taps_conv(1, 1, 0), 1);
+      one_tap_seg(a.dy, 0, 0);
+      const PackDesc& pd = P.packs[c.phases[0].pack];
+      a.N = c.N; a.Npad = pd.Npad;
+      a.dpack = (float*)pd.dpack + (size_t)pd.seg[0].nchunks * pd.Npad * BK;   // behind segment 0's chunks
+      char cb[32];
+      o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
+      const Buf& rb = bufs[c.seg[1].buf];
+      tag(o, ncls(o.impl == IMPL_WG5 ? "wg5" : "wgrad", pd.Npad, cb), short_name(c.wname) + ".raw", conv_flops(c, 1) * ((double)c.seg[1].Cw / c.Kin),
+          (double)rb.B * rb.H * rb.W * 8 * esz + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c));
+    }
     }
     // A dense layer's 1x1 bottleneck convolution: its weight gradient and its data gradient read the same three tensors; when the
     // pair qualifies (bw1.hip) the weight-gradient launch is taken back here and folded into the data-gradient launch below.
@@ -857,7 +885,10 @@ struct Builder {
     for (int l = 0; l < g.L[b]; ++l) {
       const std::string q = p + ".denselayer" + std::to_string(l + 1);
       const int K = g.cin[b] + l * g.k;
-      const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true, /*matz=*/K >= 384);
+      // (round 2: the gradient of a wide layer's bottleneck was re-gathered by two launches x K/128 column tiles; since bw1 reads it
+      // once per channel slice, with the slices of a row range on one XCD, materialising it first only adds a pass: DMM_MATZ_DENSE_K)
+      static const int matz_k = getenv("DMM_MATZ_DENSE_K") ? atoi(getenv("DMM_MATZ_DENSE_K")) : 384;
+      const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true, /*matz=*/K >= matz_k);
       const int n1 = new_bn(q + ".norm1", K);
       bn_range(n1, xb, base, 0, K);
       {

@@ -52,8 +52,9 @@ __device__ __forceinline__ typename TT<T>::vec w5_frag(const w5_u32x2& lo, const
   return __builtin_bit_cast(typename TT<T>::vec, v);
 }
 
-// PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient)
-template <typename T, int TR, int STR, int PA>
+// PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient);
+// PY = prologue of the thin operand: 1 BN+ReLU (the raw-input channels of the head's first convolution sit behind norm0), 0 none
+template <typename T, int TR, int STR, int PA, int PY>
 __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   const T* asrc = (const T*)sa.src + ca * SLOT;
   const T* asrc2 = (const T*)sa.src2 + ca * SLOT;
   const T* ysrc = (const T*)sy.src;
+  SlotK<SLOT> kyk;  // the thin operand's eight channels: the same constants for every thread
+  kyk.k0 = 0.f; kyk.k1 = 0.f; kyk.k2 = 0.f; kyk.k3 = 0.f;
+  if (PY == 1) { kyk.k0 = load_fv<SLOT>(sy.scale); kyk.k1 = load_fv<SLOT>(sy.shift); }
   int alds[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -140,7 +144,11 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
 #pragma unroll
     for (int i = 0; i < NYL; ++i) {
       const int hp = tid + NTHREADS * i;
-      if (hp < W5_HH * W5_HW) *(V*)(Ys + hp * 16) = ((R.oky >> i) & 1) ? R.ry[i] : z;
+      if (hp < W5_HH * W5_HW) {
+        V v = R.ry[i];
+        if constexpr (PY == 1) v = bn_relu_slot(R.ry[i], kyk);
+        *(V*)(Ys + hp * 16) = ((R.oky >> i) & 1) ? v : z;  // zero padding applies AFTER the prologue
+      }
     }
   };
 
@@ -220,9 +228,9 @@ static bool g_wg5 = getenv("DMM_NO_WG5") == nullptr;
 void wg5_set_enabled(bool on) { g_wg5 = on; }
 
 
-template <typename T, int TR, int STR, int PA>
+template <typename T, int TR, int STR, int PA, int PY = 0>
 static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
-  auto kern = wg5_kernel<T, TR, STR, PA>;
+  auto kern = wg5_kernel<T, TR, STR, PA, PY>;
   constexpr int lds = W5Geo<TR, STR>::LDS;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), lds, st, g);
   return hipGetLastError();
@@ -231,19 +239,21 @@ static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
 // Takes a weight gradient whose tapped operand (seg[0]) is ONE 8-channel slot and whose pixel-aligned operand (dy) has 64 channels,
 // 16-bit storage:  (a) 25 taps at stride 1, the 64 channels an activation (BN+ReLU): the head's 5x5 convolution, transposed form;
 // (b) 49 taps at stride 2 over the raw input, the 64 channels an output gradient (plain or with the deferred correction): the
-// stem's 7x7 convolution, normal form.  Returns hipErrorNotSupported otherwise.
+// stem's 7x7 convolution, normal form;  (c) 9 taps at stride 1 over the BN+ReLU-normalised raw input, the 64 channels an output
+// gradient: the raw-input segment of the head's first convolution (reference M:126-127), normal form, all four output parities of
+// the plan's phase decomposition in one pass over the full-resolution gradient.  Returns hipErrorNotSupported otherwise.
 hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   if (!family_on(g_wg5, IMPL_WG5) || dtype == DT_F32 || a.nseg != 1) return hipErrorNotSupported;
   const Seg& q = a.seg[0];
   const Seg& p = a.dy;
-  const bool stem = q.ntaps == 49;
-  const int tr = stem ? 3 : 2, str = stem ? 2 : 1;
-  if (q.mode != G_PLAIN || q.istride != str || (q.ntaps != 25 && q.ntaps != 49) || q.C != 8 || q.Cpad != 8 || q.Hs != str * a.Ho || q.Ws != str * a.Wo ||
-      q.scale != nullptr || q.q != nullptr)
+  const bool stem = q.ntaps == 49, raw3 = q.ntaps == 9;
+  const int tr = stem ? 3 : (raw3 ? 1 : 2), str = stem ? 2 : 1;
+  if (q.mode != G_PLAIN || q.istride != str || (q.ntaps != 25 && q.ntaps != 49 && q.ntaps != 9) || q.C != 8 || q.Cpad != 8 || q.Hs != str * a.Ho ||
+      q.Ws != str * a.Wo || (q.scale != nullptr) != raw3 || q.q != nullptr)
     return hipErrorNotSupported;
   if (q.nchunks != (q.ntaps * 8 + 31) / 32) return hipErrorNotSupported;
   if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo) return hipErrorNotSupported;
-  if (stem ? p.scale != nullptr : (p.scale == nullptr || p.q != nullptr)) return hipErrorNotSupported;
+  if ((stem || raw3) ? p.scale != nullptr : (p.scale == nullptr || p.q != nullptr)) return hipErrorNotSupported;
   if (a.N != W5_CA || a.Npad != W5_CA) return hipErrorNotSupported;
   bool seen[49];
   for (int t = 0; t < 49; ++t) seen[t] = false;
@@ -266,6 +276,10 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;
   nwg = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
   const bool f16t = dtype == DT_F16;
+  if (raw3) {
+    if (p.q) return f16t ? launch_wg5_t<f16, 1, 1, 2, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 2, 1>(g, nwg, st);
+    return f16t ? launch_wg5_t<f16, 1, 1, 0, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 0, 1>(g, nwg, st);
+  }
   if (!stem) return f16t ? launch_wg5_t<f16, 2, 1, 1>(g, nwg, st) : launch_wg5_t<bf16, 2, 1, 1>(g, nwg, st);
   if (p.q) return f16t ? launch_wg5_t<f16, 3, 2, 2>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 2>(g, nwg, st);
   return f16t ? launch_wg5_t<f16, 3, 2, 0>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 0>(g, nwg, st);

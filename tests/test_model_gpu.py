@@ -467,7 +467,8 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     assert all(torch.isfinite(v).all() for v in grads[1].values()) and worst < 2e-4
     # the same for the two convolutions with an 8-channel operand (wg5.hip vs the generic kernel): the head's 5x5 onto the classes
     # (transposed form) and the stem's 7x7 stride 2 over the raw input (normal form, deferred-correction prologue on the gradient)
-    names = ["dec_out_to_heat_maps.refine1.weight", "features.conv0.weight"]
+    # ... and the raw-input segment of the head's 3x3 (normal form, BN+ReLU prologue on the 8-channel operand, one pass for all four parities)
+    names = ["dec_out_to_heat_maps.refine1.weight", "features.conv0.weight", "dec_out_to_heat_maps.refine0.weight"]
     g5 = {}
     try:
         for on in (1, 0):
@@ -481,7 +482,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     finally:
         _lib.check(L.dmm_set_option(b"wg5", 1))
         model._plans.clear()
-    assert sorted(x.split("/")[1] for x in labels if x.startswith("wg5.")) == ["f.conv0", "h.refine1"], [x for x in labels if x.startswith("wg5.")]
+    assert sorted(x.split("/")[1] for x in labels if x.startswith("wg5.")) == ["f.conv0", "h.refine0.raw", "h.refine1"], [x for x in labels if x.startswith("wg5.")]
     for k in names:
         e5 = ((g5[1][k] - g5[0][k]).norm() / g5[0][k].norm()).item()
         print(f"wg5 vs generic on identical operands ({dtype}) {k}: rel L2 {e5:.3e}, max |g| {g5[0][k].abs().max().item():.3e}")
