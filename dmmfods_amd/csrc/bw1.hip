@@ -20,6 +20,9 @@
 
 namespace dmm {
 
+#ifndef B1_GOLD_EARLY
+#define B1_GOLD_EARLY 0  // 1: request the old gradient in front of the MFMAs (round 2; 16 more live registers across both GEMMs)
+#endif
 constexpr int B1_TM = 64;                       // pixels per tile
 constexpr int B1_NB = 128;                      // bottleneck channels (K of the data gradient, N of the weight gradient)
 constexpr int B1_CT = 128;                      // input channels per workgroup
@@ -91,16 +94,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     kc[2 * B1_CT + tid] = v ? a.bmean[c] : 0.f; kc[3 * B1_CT + tid] = v ? a.binvstd[c] : 0.f;
     kc[4 * B1_CT + tid] = PQ == 2 ? sg.q[tid] : 0.f; kc[5 * B1_CT + tid] = PQ == 2 ? sg.r[tid] : 0.f;
   }
-  const T* xsrc = (const T*)a.bx + (cvalid ? cx : 0);
-  const T* gsrc = (const T*)sg.src + cs * SLOT;
-  const T* ysrc = (const T*)sg.src2 + cs * SLOT;
-  T* gout = (T*)a.out + (cvalid ? cx : 0);
-  int lds[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int p = p0 + 16 * i;
-    lds[i] = p * 256 + (b1_swz(p, cs) << 4);
-  }
+  // uniform base pointers (scalar registers) + 32-bit per-lane byte offsets: four 64-bit per-lane pointers were the registers that
+  // spilled the <effective gradient, accumulate> variant (the launcher checks that every operand spans < 4 GiB)
+  const unsigned char* xbase = (const unsigned char*)a.bx;
+  const unsigned char* gbase = (const unsigned char*)sg.src;
+  const unsigned char* ybase = (const unsigned char*)sg.src2;
+  unsigned char* obase = (unsigned char*)a.out;
+  const unsigned xcol = (unsigned)(cvalid ? cx : 0) * 2u, gcol = (unsigned)(cs * SLOT) * 2u;
+  const unsigned xpitch = (unsigned)a.ldbx * 2u, gpitch = (unsigned)sg.ld * 2u, ypitch = (unsigned)sg.ld2 * 2u, opitch = (unsigned)a.ldo * 2u;
+  // (p0 + 16 i keeps p & 15, hence the row's slot permutation: the four LDS addresses of a thread are base + 4096 i)
+  const int lds0 = p0 * 256 + (b1_swz(p0, cs) << 4);
 
   // ---- the weight slice, once: chunks of 32 bottleneck channels x 128 input channels (igemm's B image, XOR swizzle) ----
   {
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     for (int i = 0; i < NL; ++i) {  // branch-free: clamped rows, dropped at the write
       const int m = tile * B1_TM + p0 + 16 * i;
       if (m < a.M) okp |= 1u << i;
-      const size_t mm = (size_t)min(m, a.M - 1);
-      rx[i] = *(const V*)(xsrc + mm * a.ldbx);
-      rg[i] = *(const V*)(gsrc + mm * sg.ld);
-      if constexpr (PQ == 2) ry[i] = *(const V*)(ysrc + mm * sg.ld2);
+      const unsigned mm = (unsigned)min(m, a.M - 1);
+      rx[i] = *(const V*)(xbase + (size_t)(mm * xpitch + xcol));
+      rg[i] = *(const V*)(gbase + (size_t)(mm * gpitch + gcol));
+      if constexpr (PQ == 2) ry[i] = *(const V*)(ybase + (size_t)(mm * ypitch + gcol));
     }
   };
 
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   auto tr_off = [&](int px, int colbyte) { return px * 256 + ((b1_swz(px, colbyte >> 4) << 4) | (colbyte & 15)); };
   // a k-step further down the tile is 16 rows = 4096 bytes further: the slot permutation of the row does not change
   const int acolb = (32 * wave + 16 * (tg & 1) + 4 * tp) * 2;
-  const int aoff1 = tr_off(arow, acolb), aoff2 = tr_off(arow + 4, acolb);
-  int goff1[4], goff2[4];
+  // the fragment's second half sits 4 rows further: (row & 3) is unchanged and (row >> 2) & 3 goes from even to odd, i.e. the slot's
+  // low bit flips: offset2 = (offset1 ^ 16) + 4 * 256 (two instructions at the use instead of five more live registers)
+  const int aoff1 = tr_off(arow, acolb);
+  int goff1[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int cb = (32 * j + 16 * (tg & 1) + 4 * tp) * 2;
-    goff1[j] = tr_off(arow, cb); goff2[j] = tr_off(arow + 4, cb);
-  }
+  for (int j = 0; j < 4; ++j) goff1[j] = tr_off(arow, (32 * j + 16 * (tg & 1) + 4 * tp) * 2);
+  auto second = [](int off) { return (off ^ 16) + 4 * 256; };
 
   f32x16 accw[4];
 #pragma unroll
@@ -167,32 +170,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     V xraw[NL], gold[ACC ? NL : 1];
     const unsigned ok = okp;
     {
-      SlotK<SLOT> kx, kg;
-      kx.k0 = load_fv<SLOT>(kc + cs * SLOT); kx.k1 = load_fv<SLOT>(kc + B1_CT + cs * SLOT); kx.k2 = 0.f; kx.k3 = 0.f;
-      kg.k0 = 0.f; kg.k1 = 0.f; kg.k2 = 0.f; kg.k3 = 0.f;
-      if (PQ == 2) { kg.k0 = load_fv<SLOT>(kc + 4 * B1_CT + cs * SLOT); kg.k1 = load_fv<SLOT>(kc + 5 * B1_CT + cs * SLOT); }
       V z;
 #pragma unroll
       for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+      {  // x first, then G: the two sets of per-channel constants are never live together
+        SlotK<SLOT> kx;
+        kx.k0 = load_fv<SLOT>(kc + cs * SLOT); kx.k1 = load_fv<SLOT>(kc + B1_CT + cs * SLOT); kx.k2 = 0.f; kx.k3 = 0.f;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        xraw[i] = rx[i];
-        const bool v = ((ok >> i) & 1) != 0;
-        *(V*)(Ai + lds[i]) = (v && cvalid) ? bn_relu_slot(rx[i], kx) : z;
-        V gv = rg[i];
-        if constexpr (PQ == 2) gv = eff_grad_slot(rg[i], ry[i], kg);
-        *(V*)(Gi + lds[i]) = v ? gv : z;
+        for (int i = 0; i < NL; ++i) {
+          xraw[i] = rx[i];
+          const bool v = ((ok >> i) & 1) != 0;
+          *(V*)(Ai + lds0 + 4096 * i) = (v && cvalid) ? bn_relu_slot(rx[i], kx) : z;
+        }
+      }
+      {
+        SlotK<SLOT> kg;
+        kg.k0 = 0.f; kg.k1 = 0.f; kg.k2 = 0.f; kg.k3 = 0.f;
+        if (PQ == 2) { kg.k0 = load_fv<SLOT>(kc + 4 * B1_CT + cs * SLOT); kg.k1 = load_fv<SLOT>(kc + 5 * B1_CT + cs * SLOT); }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const bool v = ((ok >> i) & 1) != 0;
+          V gv = rg[i];
+          if constexpr (PQ == 2) gv = eff_grad_slot(rg[i], ry[i], kg);
+          *(V*)(Gi + lds0 + 4096 * i) = v ? gv : z;
+        }
       }
     }
     __syncthreads();  // images (and, the first time, the weight slice) complete
     if (tile + 1 < t_end) issue(tile + 1);
-    if constexpr (ACC) {  // the old gradient of this tile: requested now, needed behind the MFMAs
+#if B1_GOLD_EARLY
+    if constexpr (ACC) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const size_t mm = (size_t)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
-        gold[i] = *(const V*)(gout + mm * a.ldo);
+        const unsigned mm = (unsigned)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
+        gold[i] = *(const V*)(obase + (size_t)(mm * opitch + xcol));
       }
     }
+#endif
 
     // ---- data gradient: dX[64 px][128 c] = G W ----
     f32x16 accd[2];
@@ -215,13 +229,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     // ---- weight gradient: dP[c][n] += sum over the tile's pixels G[p][n] a[p][c] ----
 #pragma unroll
     for (int ms = 0; ms < B1_TM / 16; ++ms) {
-      const V af = b1_frag<T>(b1_tr16(Ai + aoff1 + ms * 4096), b1_tr16(Ai + aoff2 + ms * 4096));
+      const V af = b1_frag<T>(b1_tr16(Ai + aoff1 + ms * 4096), b1_tr16(Ai + second(aoff1) + ms * 4096));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const V gf = b1_frag<T>(b1_tr16(Gi + goff1[j] + ms * 4096), b1_tr16(Gi + goff2[j] + ms * 4096));
+        const V gf = b1_frag<T>(b1_tr16(Gi + goff1[j] + ms * 4096), b1_tr16(Gi + second(goff1[j]) + ms * 4096));
         accw[j] = mma16(gf, af, accw[j]);  // rows: bottleneck channel n, columns: input channel c
       }
     }
+#if !B1_GOLD_EARLY
+    if constexpr (ACC) {  // the old gradient of this tile: requested behind the MFMAs (16 registers that would otherwise live across both
+                          // GEMMs), needed two barriers and the staging later; the CU's other workgroup covers what is left of the latency
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const unsigned mm = (unsigned)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
+        gold[i] = *(const V*)(obase + (size_t)(mm * opitch + xcol));
+      }
+    }
+#endif
     __syncthreads();  // all waves done with the images: stage the data-gradient tile over them
     float* Cs = (float*)smem;
 #pragma unroll
@@ -259,8 +283,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
           s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
           gf[e] = (ACC ? gf[e] : 0.f) + sc[e] * dz;
         }
-        const size_t m = (size_t)tile * B1_TM + p;
-        *(V*)(gout + m * a.ldo) = f32_to_vec<T>(gf);
+        const unsigned m = (unsigned)(tile * B1_TM + p);
+        *(V*)(obase + (size_t)(m * opitch + xcol)) = f32_to_vec<T>(gf);
       }
     }
     // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column, then fp64 in LDS
@@ -329,6 +353,8 @@ bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype) {
   if (w.N != B1_NB || w.Npad != B1_NB || w.M != d.M || d.N != wx.C || d.Npad % 32) return false;
   if (d.bx != wx.src || d.ldbx != wx.ld || d.bscale != wx.scale || d.bshift != wx.shift) return false;
   if (d.out == nullptr || d.ostride != 1 || d.Hout != d.Ho || d.Wout != d.Wo || wx.Hs != d.Ho || wx.Ws != d.Wo) return false;
+  const double span = 2.0 * (double)d.M;  // 32-bit byte offsets inside every operand
+  if (span * d.ldbx >= 4294967296.0 || span * d.ldo >= 4294967296.0 || span * dg.ld >= 4294967296.0 || span * dg.ld2 >= 4294967296.0) return false;
   return true;
 }
 

@@ -887,7 +887,8 @@ struct Builder {
       const int K = g.cin[b] + l * g.k;
       // (round 2: the gradient of a wide layer's bottleneck was re-gathered by two launches x K/128 column tiles; since bw1 reads it
       // once per channel slice, with the slices of a row range on one XCD, materialising it first only adds a pass: DMM_MATZ_DENSE_K)
-      static const int matz_k = getenv("DMM_MATZ_DENSE_K") ? atoi(getenv("DMM_MATZ_DENSE_K")) : 384;
+      // Measured (round 3, C2 b4, same box): threshold 384 / 640 / never: applycorr 2.08 / 1.81 / 1.69 ms, bw1 5.49 / 5.56 / 5.59 ms.
+      static const int matz_k = getenv("DMM_MATZ_DENSE_K") ? atoi(getenv("DMM_MATZ_DENSE_K")) : (1 << 30);
       const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true, /*matz=*/K >= matz_k);
       const int n1 = new_bn(q + ".norm1", K);
       bn_range(n1, xb, base, 0, K);
