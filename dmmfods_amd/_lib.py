@@ -78,6 +78,8 @@ def lib():
     L.dmm_plan_set_loss.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.dmm_loss_forward.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.dmm_plan_num_grad_buckets.argtypes = [vp]
+    L.dmm_plan_num_graph_replays.argtypes = [vp, C.c_int]
+    L.dmm_plan_num_graph_replays.restype = C.c_longlong
     L.dmm_plan_grad_bucket.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
     L.dmm_plan_grad_bucket_wait.argtypes = [vp, C.c_int, vp]
     L.dmm_plan_profile_begin.argtypes = [vp, C.c_int]
@@ -103,7 +105,7 @@ EXPORTS = [
     "dmm_last_error", "dmm_version", "dmm_set_option", "dmm_plan_create", "dmm_plan_destroy", "dmm_plan_num_tensors",
     "dmm_plan_tensor_info", "dmm_plan_num_params", "dmm_plan_num_buffer_elems", "dmm_plan_workspace_bytes",
     "dmm_plan_forward_flops", "dmm_plan_bind", "dmm_plan_forward", "dmm_plan_loss_backward", "dmm_plan_backward",
-    "dmm_plan_loss_metrics", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
+    "dmm_plan_loss_metrics", "dmm_plan_num_graph_replays", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
     "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
     "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused",

@@ -26,6 +26,8 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 static bool g_overlap_wgrad = getenv("DMM_NO_OVERLAP") == nullptr;
+static bool g_graph = getenv("DMM_GRAPH") != nullptr;  // off by default: see launch_list
+static unsigned long long g_option_epoch = 1;  // bumped by every dmm_set_option: captured graphs have the options of their time baked in
 static int g_bucket_mb = getenv("DMM_GRAD_BUCKET_MB") ? atoi(getenv("DMM_GRAD_BUCKET_MB")) : 25;
 
 extern "C" {
@@ -35,7 +37,9 @@ int dmm_version(void) { return 100; }
 
 int dmm_set_option(const char* name, int value) {
   if (!name) return fail(DMM_ERR_INVALID, "null argument");
+  ++g_option_epoch;
   if (std::string(name) == "overlap_wgrad") { g_overlap_wgrad = value != 0; return DMM_OK; }
+  if (std::string(name) == "graph") { g_graph = value != 0; return DMM_OK; }
   if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "conv3") { dmm::conv3_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "wg3") { dmm::wg3_set_enabled(value != 0); return DMM_OK; }
@@ -81,6 +85,9 @@ void dmm_plan_destroy(dmm_plan* plan) {
   for (void* e : plan->bucket_events) hipEventDestroy((hipEvent_t)e);
   for (void* e : plan->join_events) hipEventDestroy((hipEvent_t)e);
   for (void* s2 : plan->side_streams) hipStreamDestroy((hipStream_t)s2);
+  for (auto& gc : plan->graphs)
+    for (auto& e : gc.entries) hipGraphExecDestroy((hipGraphExec_t)e.exec);
+  if (plan->capture_stream) hipStreamDestroy((hipStream_t)plan->capture_stream);
   delete plan;
 }
 
@@ -112,6 +119,7 @@ int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float
   plan->params = params;
   plan->grads = grads;
   plan->buffers = buffers;
+  plan->graphs[0].epoch = plan->graphs[1].epoch = 0;  // captured graphs hold the old pointers
   try {
     plan_bind(plan, workspace);
   } catch (const std::exception& e) {
@@ -123,7 +131,8 @@ int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float
 }
 
 // Launches ops[begin, end) in order (end = 0: to the end of the list).
-static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_which = -1, size_t begin = 0, size_t end = 0) {
+// capturing: the calls are being recorded into a hipGraph (no profiling, no bucket events: launch_list records those behind the graph).
+static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_which = -1, size_t begin = 0, size_t end = 0, bool capturing = false) {
   if (end == 0 || end > ops.size()) end = ops.size();
   const size_t ev_offset = 0;
   const int dt = p->desc.dtype;
@@ -148,7 +157,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   // workgroups of a few microseconds; two independent chains fill the CUs that one chain leaves idle.  Per-op profiling keeps
   // everything on one stream so that the event pairs bracket each kernel alone; a FILTERED profile (one kernel class) runs
   // as in production.
-  const bool overlap = g_overlap_wgrad && (evs == nullptr || !filt.empty());
+  const bool overlap = g_overlap_wgrad && !capturing && (evs == nullptr || !filt.empty());
   constexpr int nside = 1;  // 2 and 3 side streams measured: 0.3 / 0.6 ms slower; and the leaf chains need one FIFO
   size_t nfork = 0;
   bool forked = false;
@@ -216,7 +225,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     if (e != hipSuccess) join();  // leave the main stream ordered after whatever the side stream already got
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], lst);
-    if (o.signal >= 0) {  // a gradient bucket is final on this stream from here on
+    if (o.signal >= 0 && !capturing) {  // a gradient bucket is final on this stream from here on
       while ((int)p->bucket_events.size() <= o.signal) {
         hipEvent_t be;
         if (hipEventCreateWithFlags(&be, hipEventDisableTiming) != hipSuccess) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
@@ -227,6 +236,83 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   }
   join();
   return DMM_OK;
+}
+
+// Every bucket event of the list, recorded on `st`: behind a graph replay all buckets are final at once.
+static int record_bucket_events(dmm_plan* p, const std::vector<Op>& ops, hipStream_t st) {
+  for (const Op& o : ops) {
+    if (o.signal < 0) continue;
+    while ((int)p->bucket_events.size() <= o.signal) {
+      hipEvent_t be;
+      if (hipEventCreateWithFlags(&be, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+      p->bucket_events.push_back((void*)be);
+    }
+    HIPCHK(hipEventRecord((hipEvent_t)p->bucket_events[o.signal], st));
+  }
+  return DMM_OK;
+}
+
+// Runs a whole launch list.  The launches [seg_begin, seg_end) - everything that does not touch a caller pointer - are captured ONCE
+// into a hipGraph the second time the list runs (on a plan-owned stream: the caller's may be the legacy default stream, which cannot
+// be captured) as ONE chain - the weight gradients are not sent to the side stream - and replayed by one call from then on; the few
+// launches in front of and behind the segment (input conversion, the stem convolution up to the join with the weight-packing stream,
+// the logits kernel; the loss kernel) take the caller's pointers and stay eager, so the graph never has to be patched or captured
+// again.  `which`: 0 training forward, 1 loss + backward.
+// Measured on MI355X / ROCm 7.2 (round 3, tools/host_bound.py): a replay enqueues a step in 0.5 ms of host time instead of 14 ms (C1) /
+// 25 ms (C2), but the GPU time of a step does not change (C1 18.6 ms, C2 31.7 ms replayed = the same launches eager on one stream):
+// the small configurations are bound by the latency of ~700 dependent tiny-grid kernels, not by the host, and the eager
+// two-stream schedule is faster than either (C1 16.5 ms, C2 29.5 ms).  A capture of the two-stream schedule (fork / join events
+// between the streams) replayed at 37 ms (C1) / 41 ms (C2) and returned different weight gradients than the eager launches, so the
+// capture is single-stream.  Hence OFF by default (dmm_set_option("graph", 1) / DMM_GRAPH=1): it frees the host, it does not buy time.
+static int launch_list(dmm_plan* p, int which, std::vector<Op>& ops, size_t seg_begin, size_t seg_end, hipStream_t st) {
+  dmm_plan::GraphCache& gc = p->graphs[which];
+  const bool profiling = p->prof_max_passes > 0 && p->prof_pass[which] < p->prof_max_passes;
+  if (gc.epoch != g_option_epoch) {  // an option changed (or the plan was re-bound) since the graph was captured
+    for (auto& e : gc.entries) hipGraphExecDestroy((hipGraphExec_t)e.exec);
+    gc.entries.clear();
+    gc.nseen = 0;
+    gc.epoch = g_option_epoch;
+  }
+  const bool want = g_graph && !p->graph_failed && !profiling && !(which == 1 && p->dp_used) && seg_end > seg_begin + 8;
+  if (!want) return run_ops(p, ops, st, which);
+  if (gc.entries.empty() && gc.nseen > 0) {  // the second run of the list: capture the segment
+    if (p->capture_stream == nullptr) {
+      hipStream_t cs;
+      if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail(DMM_ERR_HIP, "capture stream");
+      p->capture_stream = (void*)cs;
+    }
+    hipStream_t cs = (hipStream_t)p->capture_stream;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int rc = run_ops(p, ops, cs, -1, seg_begin, seg_end, true);
+      const bool ended = hipStreamEndCapture(cs, &graph) == hipSuccess && graph != nullptr;
+      ok = rc == DMM_OK && ended;
+      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+    }
+    gc.captures++;
+    static const bool gtrace = getenv("DMM_GRAPH_TRACE") != nullptr;
+    if (gtrace) fprintf(stderr, "[dmm] graph capture of list %d, launches [%zu, %zu): %s\n", which, seg_begin, seg_end, ok ? "ok" : "FAILED");
+    if (!ok) {
+      (void)hipGetLastError();
+      p->graph_failed = true;  // stay eager on this plan
+    } else {
+      dmm_plan::GraphEntry e;
+      for (int i = 0; i < 4; ++i) e.key[i] = nullptr;
+      e.exec = (void*)exec; e.stamp = 0;
+      gc.entries.push_back(e);
+    }
+  }
+  gc.nseen = 1;
+  if (gc.entries.empty()) return run_ops(p, ops, st, which);
+  int rc = seg_begin > 0 ? run_ops(p, ops, st, -1, 0, seg_begin) : DMM_OK;
+  if (rc) return rc;
+  HIPCHK(hipGraphLaunch((hipGraphExec_t)gc.entries[0].exec, st));
+  p->graph_replays[which]++;
+  if (seg_end < ops.size()) { rc = run_ops(p, ops, st, -1, seg_end, ops.size()); if (rc) return rc; }
+  return which == 1 ? record_bucket_events(p, ops, st) : DMM_OK;
 }
 
 int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_2, float* logits_out, int training, void* stream) {
@@ -241,7 +327,13 @@ int dmm_plan_forward(dmm_plan* plan, const float* stream_1, const float* stream_
     else { o.cv.src1 = stream_2; o.cv.src2 = nullptr; }
   }
   ops[training ? plan->logits_op_train : plan->logits_op_eval].c.logits = logits_out;
-  return run_ops(plan, ops, (hipStream_t)stream, training ? 0 : -1);
+  if (!training) return run_ops(plan, ops, (hipStream_t)stream, -1);
+  // the replayed segment: behind the join with the weight-packing stream (the launches in front of it read the caller's inputs),
+  // in front of the logits kernel (which writes the caller's tensor)
+  size_t seg_begin = 0;
+  for (size_t i = 0; i < ops.size(); ++i) if (ops[i].kind == OP_JOIN) seg_begin = i + 1;
+  if (seg_begin == 0) for (int idx : plan->convert_ops_train) seg_begin = std::max(seg_begin, (size_t)idx + 1);
+  return launch_list(plan, 0, ops, seg_begin, (size_t)plan->logits_op_train, (hipStream_t)stream);
 }
 
 static void set_loss_fields(const dmm_plan* plan, BceArgs& a) {
@@ -283,7 +375,8 @@ int dmm_plan_loss_backward(dmm_plan* plan, const float* logits, const float* tar
   b.bce.logits = logits;
   b.bce.target = target;
   set_loss_fields(plan, b.bce);
-  int rc = run_ops(plan, plan->bwd, (hipStream_t)stream, 1);
+  // the loss kernel (caller pointers, loss parameters) stays eager; everything behind it is the replayed segment
+  int rc = launch_list(plan, 1, plan->bwd, (size_t)plan->bce_op + 1, plan->bwd.size(), (hipStream_t)stream);
   if (rc) return rc;
   if (metrics_out) HIPCHK(hipMemcpyAsync(metrics_out, plan->metrics, plan->metrics_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return DMM_OK;
@@ -306,6 +399,10 @@ int dmm_plan_backward(dmm_plan* plan, const float* dlogits, void* stream) {
   return run_ops(plan, plan->bwd, st, -1, (size_t)plan->bce_op + 1, 0);
 }
 
+long long dmm_plan_num_graph_replays(const dmm_plan* plan, int which) {
+  return (plan && which >= 0 && which <= 1) ? plan->graph_replays[which] : 0;
+}
+
 int dmm_plan_num_grad_buckets(const dmm_plan* plan) { return plan ? (int)plan->buckets.size() : 0; }
 
 int dmm_plan_grad_bucket(const dmm_plan* plan, int index, int64_t* offset, int64_t* count) {
@@ -318,6 +415,7 @@ int dmm_plan_grad_bucket(const dmm_plan* plan, int index, int64_t* offset, int64
 int dmm_plan_grad_bucket_wait(dmm_plan* plan, int index, void* stream) {
   if (!plan || index < 0 || index >= (int)plan->buckets.size()) return fail(DMM_ERR_INVALID, "bucket index out of range");
   const GradBucket& b = plan->buckets[index];
+  plan->dp_used = true;  // from now on the backward runs eagerly: its bucket events must be recorded where the buckets become final
   for (int ev : {b.ev_main, b.ev_side}) {
     if (ev < 0) continue;
     if (ev >= (int)plan->bucket_events.size()) return fail(DMM_ERR_STATE, "no backward pass has been enqueued on this plan yet");

@@ -112,4 +112,19 @@ struct dmm_plan {
   // weight-gradient GEMMs run on a second stream beside the data-gradient chain (nothing reads them before unpack)
   std::vector<void*> side_streams, join_events;  // weight gradients are dealt round-robin to these
   std::vector<void*> fork_events;
+  // hipGraph replay of a launch list (capi.cpp: launch_list): instantiated graphs keyed by the caller's pointers of the call
+  struct GraphEntry { const void* key[4]; void* exec; unsigned long long stamp; };
+  struct GraphCache {
+    std::vector<GraphEntry> entries;
+    const void* seen[4][4] = {};   // the caller pointers of the last eager runs (a list is captured when its pointers come back)
+    int nseen = 0;
+    int captures = 0;
+    unsigned long long epoch = 0;  // option epoch the entries were captured under (dmm_set_option invalidates them)
+  };
+  GraphCache graphs[2];          // [0] training forward, [1] loss + backward
+  void* capture_stream = nullptr;
+  bool graph_failed = false;     // a capture did not work on this plan: stay eager
+  bool dp_used = false;          // a data-parallel reducer waits for bucket events: backward stays eager (events must be real)
+  unsigned long long graph_clock = 0;
+  long long graph_replays[2] = {0, 0};
 };

@@ -68,7 +68,7 @@ typedef struct dmm_plan dmm_plan;
 
 const char* dmm_last_error(void);
 int dmm_version(void);
-/* Kernel selection switches for tests and A/B timing: "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the
+/* Switches for tests and A/B timing: "graph" (1 = replay captured launch lists, see dmm_plan_num_graph_replays), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the
  * data-gradient chain, 0 = one stream; read at every call), and the kernel families "thin_logits" (gather-once kernel for the
  * heat-map head's last convolution), "conv3" (LDS halo-tile kernels of the multi-tap convolutions), "wg3" (the growth convolution's
  * weight gradient), "wgp" (weight gradients of the parity-phase convolutions), "wg5" (of the 5x5 head / 7x7 stem convolutions),
@@ -149,6 +149,17 @@ int dmm_plan_profile_collect(dmm_plan* plan, int which, double* ms_sum, int n, i
 
 /* Loss + metrics only (validation). */
 int dmm_plan_loss_metrics(dmm_plan* plan, const float* logits, const float* target, double* metrics_out, void* stream);
+
+/* Launch-list replay.  dmm_plan_forward (training) and dmm_plan_loss_backward run their ~350 / ~750 launches eagerly the first time;
+ * the second time, the part of the list that touches no caller pointer (everything between the stem convolution and the logits
+ * kernel; everything behind the loss kernel; as one chain on one stream) is captured once into a hipGraph
+ * and replayed by ONE call from then on, whatever tensors the caller passes.  OFF by default (dmm_set_option("graph", 1) /
+ * DMM_GRAPH=1 turn it on): measured on MI355X it cuts the host's enqueue time of a step from 14-25 ms to 0.5 ms but not the GPU's
+ * time, and the replayed chain is single-stream, i.e. slower than the eager two-stream schedule (capi.cpp, launch_list).  Any
+ * dmm_set_option drops the captured graphs.  Not replayed: profiled passes, the eval forward,
+ * dmm_plan_backward, and the backward of a plan whose gradient buckets are waited for (dmm_plan_grad_bucket_wait: data-parallel
+ * overlap needs the bucket events at their place inside the list).  which: 0 training forward, 1 loss + backward. */
+long long dmm_plan_num_graph_replays(const dmm_plan* plan, int which);
 
 /* Flat fused Adam over n fp32 elements (amsgrad unsupported).  step is 1-based. */
 int dmm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

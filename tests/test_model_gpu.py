@@ -540,3 +540,47 @@ def test_fused_dense_layer_backward_matches_separate_kernels(opt, dtype):
     assert all(torch.isfinite(v).all() for v in g1.values())
     assert e_last < (3e-3 if dtype == "fp16" else 3e-2)       # bw1 measured 6.4e-4 (fp16) / 4.6e-3 (bf16)
     assert e_all < (2e-2 if dtype == "fp16" else 1e-1)        # bw1 measured 6.6e-4 (fp16) / 5.1e-3 (bf16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,variant", [("fp32", "mid3"), ("fp16", "early")])
+def test_graph_replay_matches_eager(dtype, variant):
+    """Launch-list capture (hipGraph): training steps replayed from captured graphs against the same steps launched eagerly - forward
+    logits bit for bit (no atomics in fp32 accumulation order... the statistics are fp64 atomics: equal to rounding), gradients to
+    the order of the fp32 atomic adds - and the graphs must really be in use (replay counters), survive alternating input buffers,
+    and be dropped when an option or the loss changes."""
+    from oracle import restatement as R
+    from dmmfods_amd import _lib
+    L = _lib.lib()
+    arch = _arch(R, dict(growth_rate=32, block_config=(2, 2, 2, 2), num_init_features=64) if dtype == "fp16" else TINY, variant)
+    model = _model(arch, dtype=dtype)
+    model.load_state_dict(R.make_state(arch, seed=3))
+    model = model.to(DEV).train()
+    batches = [tuple(t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=s)) for s in (0, 1)]
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(L.dmm_set_option(b"graph", mode))
+            model._plans.clear()
+            res = []
+            keep = []                       # (different logits / input tensors every step: the replayed segment touches no caller pointer)
+            for step in range(8):
+                rgb, lidar, tgt = batches[step % 2]
+                with torch.no_grad():
+                    logits = model(rgb, lidar)
+                met = model.loss_backward(tgt)
+                keep = (keep + [logits])[-2:]
+                torch.cuda.synchronize()
+                res.append((logits.clone(), met["loss_per_class"].clone(), model.grad_arena.double().clone()))
+                model._tracked_arena.zero_()
+            plan = model._last[0]
+            out[mode] = (res, L.dmm_plan_num_graph_replays(plan.handle, 0), L.dmm_plan_num_graph_replays(plan.handle, 1))
+    finally:
+        _lib.check(L.dmm_set_option(b"graph", 0))      # (the default)
+        model._plans.clear()
+    assert out[0][1] == 0 and out[0][2] == 0
+    assert out[1][1] >= 4 and out[1][2] >= 4, out[1][1:]        # the later steps were replays
+    for (lg0, ls0, g0), (lg1, ls1, g1) in zip(out[0][0], out[1][0]):
+        assert float((lg0 - lg1).abs().max()) <= 1e-6 * float(lg0.abs().max())
+        assert _rel(ls1, ls0) < 1e-6
+        assert ((g1 - g0).norm() / g0.norm()).item() < (1e-5 if dtype == "fp32" else 2e-3)
