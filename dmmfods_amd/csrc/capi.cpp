@@ -47,6 +47,7 @@ int dmm_set_option(const char* name, int value) {
   if (std::string(name) == "wg5") { dmm::wg5_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "cvp") { dmm::cvp_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "bw1") { dmm::bw1_set_enabled(value != 0); return DMM_OK; }
+  if (std::string(name) == "pig") { dmm::pig_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "grad_bucket_mb") {  // applies to plans created afterwards; 0 = one bucket
     if (value < 0) return fail(DMM_ERR_INVALID, "grad_bucket_mb must be >= 0");
     g_bucket_mb = value;

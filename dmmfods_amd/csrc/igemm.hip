@@ -703,6 +703,7 @@ hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st);  
 hipError_t launch_thin_logits(const ConvArgs& a, int dtype, int epi, hipStream_t st);  // thin.hip
 hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st);        // conv3.hip
 hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st);          // cvp.hip
+hipError_t launch_pig(const ConvArgs& a, int dtype, int epi, hipStream_t st);          // pig.hip
 
 // One translation unit per storage type (IGEMM_PART = 0 fp32, 1 f16, 2 bf16; see the Makefile): the ~50 kernel instantiations
 // of a type compile in parallel with the other types'.
@@ -735,6 +736,8 @@ static hipError_t dispatch_special(const ConvArgs& a, int dtype, int epi, hipStr
   if ((e = launch_conv3(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_CVP;    // forward of the ConvTranspose parity phases: halo tile per 128-channel group, a tap is a fragment address
   if ((e = launch_cvp(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_PIG;    // plain 1x1 convolutions, forward: persistent workgroups (next tile's loads under this tile's epilogue)
+  if ((e = launch_pig(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_HALO;   // multi-tap layers whose weights fit in LDS may take the halo-tile kernel
   if ((e = launch_halo(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_GENERIC;

@@ -162,6 +162,7 @@ void wgp_set_enabled(bool on);    // wgp.hip
 void wg5_set_enabled(bool on);    // wg5.hip
 void cvp_set_enabled(bool on);    // cvp.hip
 void bw1_set_enabled(bool on);    // bw1.hip
+void pig_set_enabled(bool on);    // pig.hip
 bool cvp_handles(const ConvArgs& a, int dtype, int epi);
 bool conv3_handles(const ConvArgs& a, int dtype, int epi);
 bool wg3_handles(const WgradArgs& a, int dtype);

@@ -72,7 +72,8 @@ int dmm_version(void);
  * data-gradient chain, 0 = one stream; read at every call), and the kernel families "thin_logits" (gather-once kernel for the
  * heat-map head's last convolution), "conv3" (LDS halo-tile kernels of the multi-tap convolutions), "wg3" (the growth convolution's
  * weight gradient), "wgp" (weight gradients of the parity-phase convolutions), "wg5" (of the 5x5 head / 7x7 stem convolutions),
- * "cvp" (the ConvTranspose kernels), "bw1" (fused backward of the 1x1 bottleneck convolutions): 1 = on, 0 = generic kernels.
+ * "cvp" (the ConvTranspose kernels), "bw1" (fused backward of the 1x1 bottleneck convolutions), "pig" (persistent forward of the
+ * 1x1 convolutions): 1 = on, 0 = generic kernels.
  * A plan chooses the family of each of its launches ONCE, in dmm_plan_bind, from the switches of that moment, and keeps it
  * (labels reported by dmm_plan_profile_op name the kernels that really run): toggle a switch BEFORE binding a plan.  The
  * single-kernel entry points below read the switches at every call.  "grad_bucket_mb": size of the data-parallel gradient
