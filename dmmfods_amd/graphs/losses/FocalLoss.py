@@ -16,47 +16,61 @@ from ... import _lib
 
 
 class _HipLoss(torch.autograd.Function):
+    """Unreduced loss of `dmm_loss_forward` on a (B, C, H, W) view; alpha / gamma per class (channels are processed eight at a time,
+    the kernel's limit).  Returns the input's dtype, like the torch expression of the reference."""
+
     @staticmethod
     def forward(ctx, inputs, targets, kind, from_prob, alpha, gamma):
         if not inputs.is_cuda:
             raise RuntimeError("dmmfods_amd computes on the GPU only; move the tensors to 'cuda' (no CPU fallback)")
-        if inputs.dim() != 4 or inputs.shape != targets.shape:
-            raise ValueError("expected inputs and targets of the same (batches, classes, X, Y) shape")
+        if inputs.shape != targets.shape:
+            raise ValueError("expected inputs and targets of the same shape")
         B, NC, H, W = inputs.shape
-        if NC > 8:
-            raise ValueError("at most 8 classes are supported")
         x = inputs.detach().contiguous().float()
         t = targets.detach().contiguous().float()
         loss = torch.empty_like(x)
         dx = torch.empty_like(x)
-        a = (C.c_float * NC)(*alpha)
-        g = (C.c_float * NC)(*gamma)
-        _lib.check(_lib.lib().dmm_loss_forward(kind, 1 if from_prob else 0, a, g, x.data_ptr(), t.data_ptr(), loss.data_ptr(),
-                                               dx.data_ptr(), B, NC, H, W, _lib.stream_ptr()))
+        L = _lib.lib()
+        if NC <= 8:
+            a = (C.c_float * NC)(*alpha)
+            g = (C.c_float * NC)(*gamma)
+            _lib.check(L.dmm_loss_forward(kind, 1 if from_prob else 0, a, g, x.data_ptr(), t.data_ptr(), loss.data_ptr(),
+                                          dx.data_ptr(), B, NC, H, W, _lib.stream_ptr()))
+        else:   # eight channels per launch on contiguous copies of the channel groups
+            for c0 in range(0, NC, 8):
+                n = min(8, NC - c0)
+                xs, ts = x[:, c0:c0 + n].contiguous(), t[:, c0:c0 + n].contiguous()
+                ls, ds = torch.empty_like(xs), torch.empty_like(xs)
+                a = (C.c_float * n)(*alpha[c0:c0 + n])
+                g = (C.c_float * n)(*gamma[c0:c0 + n])
+                _lib.check(L.dmm_loss_forward(kind, 1 if from_prob else 0, a, g, xs.data_ptr(), ts.data_ptr(), ls.data_ptr(),
+                                              ds.data_ptr(), B, n, H, W, _lib.stream_ptr()))
+                loss[:, c0:c0 + n], dx[:, c0:c0 + n] = ls, ds
         ctx.save_for_backward(dx)
-        return loss
+        ctx.in_dtype = inputs.dtype
+        return loss.to(inputs.dtype)
 
     @staticmethod
     def backward(ctx, grad_out):
         (dx,) = ctx.saved_tensors
-        return grad_out * dx, None, None, None, None, None
+        return (grad_out.float() * dx).to(ctx.in_dtype), None, None, None, None, None
 
 
 class FocalLoss(nn.Module):
-    """F = alpha * (1 - exp(-BCE))**gamma * BCE, unreduced unless ``reduce`` (then the mean).  ``logits=False``: the inputs
-    are probabilities (F.binary_cross_entropy), as in the reference's default."""
+    """F = alpha * (1 - exp(-BCE))**gamma * BCE, unreduced unless ``reduce`` (then the mean), on tensors of ANY shape (reference
+    L:30-50).  ``logits=False``: the inputs are probabilities (F.binary_cross_entropy), as in the reference's default."""
 
     def __init__(self, alpha=1, gamma=2, logits=False, reduce=True):
         super().__init__()
         self.alpha, self.gamma, self.logits, self.reduce = alpha, gamma, logits, reduce
 
-    def _per_class(self, nclass):
-        def expand(v):
+    def _per_class(self, nclass, exact=True):
+        def expand(v, pad):
             v = [float(v)] * nclass if not hasattr(v, "__len__") else [float(e) for e in v]
-            if len(v) != nclass:
+            if len(v) > nclass or (exact and len(v) != nclass):
                 raise ValueError(f"expected {nclass} per-class values, got {len(v)}")
-            return v
-        return expand(self.alpha), expand(self.gamma)
+            return v + [pad] * (nclass - len(v))
+        return expand(self.alpha, 0.0), expand(self.gamma, 1.0)
 
     def attach(self, model):
         """Select this loss as the epilogue of the model's fused training tail (logits only, as the tail sees logits)."""
@@ -67,15 +81,35 @@ class FocalLoss(nn.Module):
         return model
 
     def forward(self, inputs, targets):
-        alpha, gamma = self._per_class(inputs.shape[1] if inputs.dim() == 4 else 0)
-        loss = _HipLoss.apply(inputs, targets, _lib.LOSS_FOCAL, not self.logits, alpha, gamma)
+        # scalar alpha / gamma act element-wise: any shape is one "class" of numel elements
+        shape = inputs.shape
+        x = inputs.reshape(1, 1, 1, -1)
+        t = targets.reshape(1, 1, 1, -1)
+        alpha, gamma = [float(self.alpha)], [float(self.gamma)]
+        loss = _HipLoss.apply(x, t, _lib.LOSS_FOCAL, not self.logits, alpha, gamma).reshape(shape)
         return loss.mean() if self.reduce else loss
 
 
 class ClassWiseFocalLoss(FocalLoss):
-    """Per-class alpha (class-class imbalance) and gamma (class-background imbalance); inputs are (B, C, H, W)."""
+    """Per-class alpha (class-class imbalance) and gamma (class-background imbalance); inputs are (B, C, H, W).  As in the reference
+    (L:78-91, a loop over zip(alpha, gamma)) classes beyond the listed values get zero loss."""
 
     def __init__(self, alpha=(1, 1, 1), gamma=(2, 2, 2), logits=True, reduce=False):
         super().__init__(list(alpha), list(gamma), logits, reduce)
         if len(self.alpha) != len(self.gamma):
             raise ValueError("alpha and gamma must have the same length")
+
+    def forward(self, inputs, targets):
+        if inputs.dim() != 4:
+            raise ValueError("expected inputs and targets structured like batches x classes x X x Y")
+        n = min(len(self.alpha), len(self.gamma))
+        if n > inputs.shape[1]:
+            raise IndexError(f"{n} per-class values for {inputs.shape[1]} classes")   # the reference's F_loss[:, i] raises the same
+        self_alpha, self_gamma = self.alpha, self.gamma
+        self.alpha, self.gamma = self_alpha[:n], self_gamma[:n]
+        try:
+            alpha, gamma = self._per_class(inputs.shape[1], exact=False)
+        finally:
+            self.alpha, self.gamma = self_alpha, self_gamma
+        loss = _HipLoss.apply(inputs, targets, _lib.LOSS_FOCAL, not self.logits, alpha, gamma)
+        return loss.mean() if self.reduce else loss
