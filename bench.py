@@ -119,10 +119,11 @@ def measured_traffic(cls, workload):
         # rocprof sees kernel names, not the plan's labels: the generic weight-gradient kernel (normal and transposed form) is one
         # class there ("wgrad*.nN"); it stands for the plan's "wgrad.nN" when the launch counts of the step agree
         e = d.get("classes", {}).get(cls) or d.get("classes", {}).get(cls.replace("wgrad.", "wgrad*."))
+        pmc_cls = cls
         if e is None and cls.startswith("bw1."):   # one kernel, labelled by the padded input width in the plan: the PMC class is "bw1"
-            e = d.get("classes", {}).get("bw1")
+            e, pmc_cls = d.get("classes", {}).get("bw1"), "bw1 (all launches of the kernel: the profiler sees the kernel name, not the plan's n128 / n64 label)"
         if e:
-            return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+            return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))), pmc_cls
     return None
 
 
@@ -158,7 +159,7 @@ def roofline_block(classes, dtype, workload=None, timed=None):
     roof["traffic"] = None
     tr = measured_traffic(cls, workload)
     if tr is not None:
-        roof["traffic"], roof["traffic_source"] = tr
+        roof["traffic"], roof["traffic_source"], roof["traffic_class"] = tr
     roof["kernel"] = cls
     roof["avg_launch_ms"] = round(e["ms"] / max(e["launches"], 1), 4)
     roof["avg_launch_ms_alone"] = round(alone_ms, 4)

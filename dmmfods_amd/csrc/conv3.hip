@@ -20,6 +20,7 @@
 // LDS image of the wide segment: pixel pitch = C*2 + 16 bytes (an odd number of 16-byte slots), row pitch a multiple of 256
 // bytes: the 16 lanes of a ds_read_b128 group (pixels x = 0-3, 12-15 of one tile row and 4-11 of the next) hit 16 different slots.
 // Two workgroups share a CU (<= 80 KB of LDS each): one fills its halo while the other runs its MFMAs.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -38,7 +39,7 @@ constexpr int C3_WRING = 3;  // weight ring slots
 
 struct Conv3Args {
   ConvArgs c;
-  int tiles_y, tiles_x;
+  int tiles_y, tiles_x, ntiles;
   int dymin0, dxmin0;  // smallest tap offsets of segment 0 (its halo starts there)
   int dymin1, dxmin1;  // ... of the raw-input segment (stride-2 source)
 };
@@ -102,11 +103,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
-  const int ty_i = tile % g.tiles_y;
-  const int b = tile / g.tiles_y;
-  const int y0 = ty_i * C3_TH, x0 = tx_i * C3_TW;
+  // A workgroup walks tiles lt, lt + gridDim.x, ... of the launch (gridDim.x is a multiple of 8 whenever there is more than one
+  // round, so a workgroup stays on "its" XCD's contiguous range of the tile order): the halo loads of the NEXT tile are issued right
+  // behind the last MFMA of the current one and fly under its epilogue (round 3 ablation: load wait, K loop and epilogue of a tile
+  // simply added up - 0.5 + 0.85 + 0.6 ms on the head's forward phases - overlapped only across the 2-3 workgroups of a CU).
+  int lt = blockIdx.x;
+  int b, y0, x0;
+  auto decode = [&](int l) {
+    int tile = xcd_remap(l, g.ntiles);
+    const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty_i = tile % g.tiles_y;
+    b = tile / g.tiles_y;
+    y0 = ty_i * C3_TH; x0 = tx_i * C3_TW;
+  };
+  decode(lt);
 
   // ---- the first two weight groups start streaming now ----
   // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain it (vmcnt(0)) in front of the next ds_read
@@ -134,9 +144,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
                    : "=&s"(keep) : "v"(s + woff[q]), "s"(dst + q * 1024) : "memory");
     }
   };
-  issue_w(0);
-  if (NGRP > 1) issue_w(1);
-
   // ---- halo: every slot loaded once, all loads in flight together ----
   const int cs = tid % CSD, hp0 = tid / CSD;
   SlotK<SLOT> kk, kk1;
@@ -149,39 +156,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   bool ok[NI], okb[SEG1 ? NI1 : 1];
   const T* src = (const T*)sg.src + cs * SLOT;
   const T* src2 = (const T*)sg.src2 + cs * SLOT;
-  if constexpr (SEG0)
+  auto load_halo = [&]() {  // of tile (b, y0, x0)
+    if constexpr (SEG0)
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int hp = hp0 + PSTEP * i;
-    const int hy = hp / HW, hx = hp - hy * HW;
-    const int sy = y0 + g.dymin0 + hy, sx = x0 + g.dxmin0 + hx;
-    ok[i] = hp < HH * HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws;
-    // branch-free: a slot outside the picture loads a clamped (valid) address and is zeroed when the image is written; a
-    // conditional load would make the compiler wait for each load before the next branch
-    const int cy = min(max(sy, 0), sg.Hs - 1), cx = min(max(sx, 0), sg.Ws - 1);
-    const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg.Hs + cy) * sg.Ws + cx;
-    raw[i] = *(const V*)(src + pix * sg.ld);
-    if constexpr (PRO == 2) raw2[i] = *(const V*)(src2 + pix * sg.ld2);
-  }
-  if constexpr (SEG1) {
-#pragma unroll
-    for (int i = 0; i < NI1; ++i) {
-      const int hp = tid + NTHREADS * i;
-      const int hy = hp / SM::HW1, hx = hp - hy * SM::HW1;
-      const int sy = TSTR * y0 + g.dymin1 + hy, sx = TSTR * x0 + g.dxmin1 + hx;
-      okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
-      const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
-      const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
-      rawb[i] = *(const V*)((const T*)sg1.src + pix * sg1.ld);
+    for (int i = 0; i < NI; ++i) {
+      const int hp = hp0 + PSTEP * i;
+      const int hy = hp / HW, hx = hp - hy * HW;
+      const int sy = y0 + g.dymin0 + hy, sx = x0 + g.dxmin0 + hx;
+      ok[i] = hp < HH * HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws;
+      // branch-free: a slot outside the picture loads a clamped (valid) address and is zeroed when the image is written; a
+      // conditional load would make the compiler wait for each load before the next branch
+      const int cy = min(max(sy, 0), sg.Hs - 1), cx = min(max(sx, 0), sg.Ws - 1);
+      const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg.Hs + cy) * sg.Ws + cx;
+      raw[i] = *(const V*)(src + pix * sg.ld);
+      if constexpr (PRO == 2) raw2[i] = *(const V*)(src2 + pix * sg.ld2);
     }
-  }
-  if (tid < BM) {
-    const int y = y0 + tid / C3_TW, x = x0 + tid % C3_TW;
-    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
-  }
-  if (tid < 2 * BN) red[tid] = 0.0;
-
-  // ---- epilogue operands of the fused BN/ReLU backward: x at every output position, issued now, used after the K loop ----
+    if constexpr (SEG1) {
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) {
+        const int hp = tid + NTHREADS * i;
+        const int hy = hp / SM::HW1, hx = hp - hy * SM::HW1;
+        const int sy = TSTR * y0 + g.dymin1 + hy, sx = TSTR * x0 + g.dxmin1 + hx;
+        okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
+        const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
+        const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
+        rawb[i] = *(const V*)((const T*)sg1.src + pix * sg1.ld);
+      }
+    }
+  };
+  load_halo();
   constexpr int NCV = BN / SLOT;       // slot columns of the output tile
   constexpr int RPP = NTHREADS / NCV;  // rows per pass
   constexpr int NIT = BM / RPP;        // rows per thread
@@ -190,6 +193,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   const bool colvalid = n < a.N;
   int ppre[EPI == EPI_BNBWD ? NIT : 1];
   V xpre[EPI == EPI_BNBWD ? NIT : 1];
+  V z;
+#pragma unroll
+  for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+  // this lane's pixel: tile row 2*wave + (r >> 4), column r & 15
+  const int ty = 2 * wave + (r >> 4), tx = r & 15;
+  const int abase = (ty - g.dymin0) * RP + (tx - g.dxmin0) * PP + h * 16;
+  const int bsw = (r >> 2) & 3;
+  // tap offsets: scalar loads from the kernel arguments, all before the loop - no compiler-counted memory operation may sit
+  // between the DMA issue and the counted wait, or hipcc's wait for it drains the DMA as well
+  int toffs[SEG0 ? SM::NTAPS0 : 1];
+  if constexpr (SEG0)
+#pragma unroll
+  for (int tap = 0; tap < SM::NTAPS0; ++tap) {
+    const int tw = sg.taps[tap];
+    toffs[tap] = (int)(signed char)(tw & 0xff) * RP + (int)(signed char)((tw >> 8) & 0xff) * PP;
+  }
+  // thin segment: one 16-byte slot per tap; k-step (chunk c, half s) of lane half h reads tap j = 4c + 2s + h (j >= taps: zeros)
+  constexpr int NT1 = SM::NTAPS1;
+  int off1[SEG1 ? 2 * SM::NCH1 : 1];
+  if constexpr (SEG1) {
+    const int abase1 = (TSTR * ty - g.dymin1) * RP1 + (TSTR * tx - g.dxmin1) * 16;
+#pragma unroll
+    for (int c = 0; c < SM::NCH1; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j0 = 4 * c + 2 * s;  // tap of lane half 0; half 1 reads j0 + 1
+        const int t0 = sg1.taps[j0 < NT1 ? j0 : 0], t1 = sg1.taps[j0 + 1 < NT1 ? j0 + 1 : 0];
+        const int o0 = (int)(signed char)(t0 & 0xff) * RP1 + (int)(signed char)((t0 >> 8) & 0xff) * 16;
+        const int o1 = (int)(signed char)(t1 & 0xff) * RP1 + (int)(signed char)((t1 >> 8) & 0xff) * 16;
+        off1[2 * c + s] = (j0 + h < NT1) ? abase1 + (h ? o1 : o0) : -1;
+      }
+  }
+
+  while (true) {   // ---- one tile (b, y0, x0); its halo is in the registers ----
+  issue_w(0);      // the first two weight groups start streaming now (the ring is free: the previous tile's staging has been read)
+  if (NGRP > 1) issue_w(1);
+  if (tid < BM) {
+    const int y = y0 + tid / C3_TW, x = x0 + tid % C3_TW;
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
+  }
+  if (tid < 2 * BN) red[tid] = 0.0;
+
+  // ---- epilogue operands of the fused BN/ReLU backward: x at every output position, issued now, used after the K loop ----
   if constexpr (EPI == EPI_BNBWD) {
     const T* bx = (const T*)a.bx;
 #pragma unroll
@@ -204,9 +250,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   }
 
   // ---- prologue once per element, then the LDS images ----
-  V z;
-#pragma unroll
-  for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
   if constexpr (SEG0)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -238,36 +281,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  // this lane's pixel: tile row 2*wave + (r >> 4), column r & 15
-  const int ty = 2 * wave + (r >> 4), tx = r & 15;
-  const int abase = (ty - g.dymin0) * RP + (tx - g.dxmin0) * PP + h * 16;
-  const int bsw = (r >> 2) & 3;
-  // tap offsets: scalar loads from the kernel arguments, all before the loop - no compiler-counted memory operation may sit
-  // between the DMA issue and the counted wait, or hipcc's wait for it drains the DMA as well
-  int toffs[SEG0 ? SM::NTAPS0 : 1];
-  if constexpr (SEG0)
-#pragma unroll
-  for (int tap = 0; tap < SM::NTAPS0; ++tap) {
-    const int tw = sg.taps[tap];
-    toffs[tap] = (int)(signed char)(tw & 0xff) * RP + (int)(signed char)((tw >> 8) & 0xff) * PP;
-  }
-  // thin segment: one 16-byte slot per tap; k-step (chunk c, half s) of lane half h reads tap j = 4c + 2s + h (j >= taps: zeros)
-  constexpr int NT1 = SM::NTAPS1;
-  int off1[SEG1 ? 2 * SM::NCH1 : 1];
-  if constexpr (SEG1) {
-    const int abase1 = (TSTR * ty - g.dymin1) * RP1 + (TSTR * tx - g.dxmin1) * 16;
-#pragma unroll
-    for (int c = 0; c < SM::NCH1; ++c)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int j0 = 4 * c + 2 * s;  // tap of lane half 0; half 1 reads j0 + 1
-        const int t0 = sg1.taps[j0 < NT1 ? j0 : 0], t1 = sg1.taps[j0 + 1 < NT1 ? j0 + 1 : 0];
-        const int o0 = (int)(signed char)(t0 & 0xff) * RP1 + (int)(signed char)((t0 >> 8) & 0xff) * 16;
-        const int o1 = (int)(signed char)(t1 & 0xff) * RP1 + (int)(signed char)((t1 >> 8) & 0xff) * 16;
-        off1[2 * c + s] = (j0 + h < NT1) ? abase1 + (h ? o1 : o0) : -1;
-      }
-  }
 
 #pragma unroll
   for (int grp = 0; grp < NGRP; ++grp) {
@@ -307,8 +320,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     if (grp + 2 < NGRP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  if ((C3_DBG & 8) && acc[0][0] != 123.f) return;
-  // all waves are past the last barrier: the images and the ring are dead, reuse them for staging
+  // all waves are past the last barrier: the images and the ring are dead.  The next tile's halo is requested NOW, so that the loads
+  // fly under this tile's epilogue; rowpix / ppre of this tile stay valid (b, y0, x0 are only read again at the top of the loop).
+  // (forward variants only: the data-gradient variants carry their epilogue operands in registers across the K loop, and holding
+  // the next halo as well costs them a workgroup per CU - measured 1.87 -> 2.6 ms on the dense 3x3 data gradients)
+  constexpr bool PERSIST = EPI == EPI_STORE;
+  const int lnext = lt + gridDim.x;
+  const bool more = PERSIST && lnext < g.ntiles;   // (workgroup-uniform)
+  if (more) { decode(lnext); load_halo(); }
+  if (!((C3_DBG & 8) && acc[0][0] != 123.f)) {
+  // reuse the images for staging
   T* Cs = (T*)smem;
   constexpr int CPITCH = BN + 8;
   float ps1[NT], ps2[NT];  // forward: this lane's column sums over its 16 rows, of the values as stored (rounded to T)
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       if (pix < 0 || !colvalid) continue;
       *(V*)(out + (size_t)pix * a.ldo + n) = *(const V*)(Cs + row * CPITCH + cv * SLOT);
     }
-    if (a.stat_sum == nullptr || (C3_DBG & 32)) return;
+    if (!(a.stat_sum == nullptr || (C3_DBG & 32)))
     if (!(C3_DBG & 16) && tid < 2 * BN) {
       const int col = tid % BN, which = tid / BN;
       if (col < a.N) {
@@ -355,7 +376,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
         atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + col, s);
       }
     }
-    return;
   } else {  // EPI_BNBWD: acc = d(relu(bn(x))); mask, reduce, scatter s*dz (see igemm.hip)
     float s1[SLOT], s2[SLOT];
 #pragma unroll
@@ -383,7 +403,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       }
       if (gout != nullptr) *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
     }
-    if (C3_DBG & 32) return;
     // per-channel reductions: lanes -> LDS (fp64) -> one fp64 atomic per channel and workgroup (see igemm.hip)
 #pragma unroll
     for (int i = 0; i < SLOT; ++i) {
@@ -401,12 +420,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       }
     }
     __syncthreads();
-    if (!(C3_DBG & 16) && tid < BN && tid < a.N) {
+    if (!(C3_DBG & (16 | 32)) && tid < BN && tid < a.N) {
       const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
       atomic_add_f64(a.red1 + rep + tid, red[tid]);
       atomic_add_f64(a.red2 + rep + tid, red[BN + tid]);
     }
   }
+  }  // (epilogue)
+  if (!more) break;
+  lt = lnext;
+  __syncthreads();  // staging / reduction scratch read: the next tile may overwrite the images, the ring, rowpix and red
+  }  // (tile loop)
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -426,7 +450,15 @@ static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.c.B * g.tiles_y * g.tiles_x), dim3(NTHREADS), SM::bytes, st, g);
+  // persistent: the workgroups a CU holds at a time (LDS, <= 4) x CUs x 2 rounds' worth of slots, in whole groups of 8 (one per XCD);
+  // a launch with fewer tiles than that runs one tile per workgroup, as before
+  static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
+                              return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  static const int rounds = getenv("DMM_C3_ROUNDS") ? atoi(getenv("DMM_C3_ROUNDS")) : 1;
+  const int per_cu = std::min(4, (160 * 1024) / SM::bytes);
+  int nwg = g.ntiles;
+  if (EPI == EPI_STORE && rounds > 0 && nwg > per_cu * cus * rounds) nwg = per_cu * cus * rounds / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), SM::bytes, st, g);
   return hipGetLastError();
 }
 
@@ -506,6 +538,7 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
   g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
   g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
+  g.ntiles = a.B * g.tiles_y * g.tiles_x;
   const int nt = a.Npad / 32;
   static const bool trace = getenv("DMM_C3_TRACE") != nullptr;
   if (trace && !g_ctl.dry) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);

@@ -23,6 +23,10 @@ def classify(name):
     m = re.search(r"conv3_kernelI(?:DF16_|DF16b)Li\d+ELi\d+ELin?\d+ELi\d+ELi(\d+)ELi\d+ELi(\d+)ELi\d+E", name)
     if m:
         return f"conv3.{EPI.get(m.group(2), m.group(2))}.n{32 * int(m.group(1))}"
+    if "pig_kernel" in name:
+        return "pig.store.n128"
+    if "thin_logits_kernel" in name:
+        return "thin.logits.n32"
     if "wg3_kernel" in name:
         return "wg3.n128"
     if "wgp_kernel" in name:
