@@ -20,6 +20,11 @@
 
 namespace dmm {
 
+#ifndef B1_DBG
+#define B1_DBG 0  // timing experiments only (tools/build_variant.sh ... -DB1_DBG=n): 1 no weight-gradient atomics, 2 no weight-gradient
+                  // GEMM, 4 no data-gradient GEMM, 8 no epilogue (staging, norm1 backward, store), 16 every load hits row 0,
+                  // 32 the old gradient is not read (as if not accumulating), 64 the gradient is not stored
+#endif
 #ifndef B1_GOLD_EARLY
 #define B1_GOLD_EARLY 0  // 1: request the old gradient in front of the MFMAs (round 2; 16 more live registers across both GEMMs)
 #endif
@@ -53,8 +58,9 @@ __device__ __forceinline__ typename TT<T>::vec b1_frag(const b1_u32x2& lo, const
 
 // PQ = prologue of G: 0 none (materialised gradient), 2 effective gradient.  ACC = the gradient of x is accumulated (an earlier
 // consumer of the block buffer has already written it).
-template <typename T, int PQ, bool ACC>
+template <typename T, int PQ, bool ACC_>
 __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
+  constexpr bool ACC = ACC_ && !(B1_DBG & 32);
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
   constexpr int SLOT = 8;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     for (int i = 0; i < NL; ++i) {  // branch-free: clamped rows, dropped at the write
       const int m = tile * B1_TM + p0 + 16 * i;
       if (m < a.M) okp |= 1u << i;
-      const unsigned mm = (unsigned)min(m, a.M - 1);
+      const unsigned mm = (B1_DBG & 16) ? 0u : (unsigned)min(m, a.M - 1);
       rx[i] = *(const V*)(xbase + (size_t)(mm * xpitch + xcol));
       rg[i] = *(const V*)(gbase + (size_t)(mm * gpitch + gcol));
       if constexpr (PQ == 2) ry[i] = *(const V*)(ybase + (size_t)(mm * ypitch + gcol));
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) accd[t][i] = 0.f;
+    if (!(B1_DBG & 4))
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
         }
       }
     // ---- weight gradient: dP[c][n] += sum over the tile's pixels G[p][n] a[p][c] ----
+    if (!(B1_DBG & 2))
 #pragma unroll
     for (int ms = 0; ms < B1_TM / 16; ++ms) {
       const V af = b1_frag<T>(b1_tr16(Ai + aoff1 + ms * 4096), b1_tr16(Ai + second(aoff1) + ms * 4096));
@@ -247,6 +255,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     }
 #endif
     __syncthreads();  // all waves done with the images: stage the data-gradient tile over them
+    if (B1_DBG & 8) {  // keep the data-gradient GEMM alive
+      float sa = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa += accd[t][i];
+      if (sa == 1.2345e33f) obase[0] = 1;
+    } else {
     float* Cs = (float*)smem;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -284,22 +300,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
           gf[e] = (ACC ? gf[e] : 0.f) + sc[e] * dz;
         }
         const unsigned m = (unsigned)(tile * B1_TM + p);
-        *(V*)(obase + (size_t)(m * opitch + xcol)) = f32_to_vec<T>(gf);
+        if (!(B1_DBG & 64) || gf[0] == 1.2345e33f) *(V*)(obase + (size_t)(m * opitch + xcol)) = f32_to_vec<T>(gf);
       }
     }
-    // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column, then fp64 in LDS
+    // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column (lane swaps: every lane ends
+    // up with 4 of the 16 finished wave totals), then fp64 in LDS - 4 LDS atomics per lane instead of 16 on a quarter of the lanes
+    {
+      float v[2 * SLOT], w[SLOT / 2];
 #pragma unroll
-    for (int e = 0; e < SLOT; ++e) {
-      s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
-      s2[e] += __shfl_xor(s2[e], 16, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
-    }
-    if (cvalid && lane < 16) {
+      for (int e = 0; e < SLOT; ++e) { v[e] = s1[e]; v[SLOT + e] = s2[e]; }
+      fold_rows<SLOT / 2>(v, w);
+      if (cvalid) {
+        const int pick = fold_pick(lane);
 #pragma unroll
-      for (int e = 0; e < SLOT; ++e) {
-        atomicAdd(&red[cs * SLOT + e], (double)s1[e]);
-        atomicAdd(&red[B1_CT + cs * SLOT + e], (double)s2[e]);
+        for (int m = 0; m < SLOT / 2; ++m) {  // value 4 m + pick: m < 2 -> s1[4 m + pick], else s2[4 (m - 2) + pick]
+          const int vi = 4 * m + pick;
+          atomicAdd(&red[(m >= SLOT / 4 ? B1_CT : 0) + cs * SLOT + (vi & (SLOT - 1))], (double)w[m]);
+        }
       }
     }
+    }  // (epilogue)
     __syncthreads();  // staging read: the next tile's images may be written
   }
 
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     atomic_add_f64(a.red2 + rep + c0 + tid, red[B1_CT + tid]);
   }
   const int c = c0 + 32 * wave + r;
-  if (c < g.wC) {
+  if (!(B1_DBG & 1) && c < g.wC) {
     const size_t chunk = (size_t)(c0 / 32 + wave);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -319,6 +339,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
         const int n = 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h;
         atomic_add_f32(g.dpack + (chunk * g.dNpad + n) * 32 + r, accw[j][i]);
       }
+  }
+  if (B1_DBG & 1) {  // keep the weight-gradient GEMM alive
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += accw[j][i];
+    if (s == 1.2345e33f) g.dpack[0] = s;
   }
 }
 

@@ -390,6 +390,36 @@ __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSl
 }
 
 // Decompose a row index into (b, y, x) of the row grid.
+// Sums of per-lane partials over the four 16-lane rows of a wave with the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap:
+// VALU, no LDS round trip).  A swap exchanges halves (rows) of TWO registers, so one swap + one add folds two values at once:
+// 16 values cost 12 swaps + 12 adds (two __shfl_xor steps per value: 32 ds_bpermute + 32 adds) and leave every lane with ONE
+// finished wave total per group of four values instead of all of them in every lane.
+//   in:  v[0 .. 4 NQ)   this lane's partials
+//   out: w[m], m < NQ = the wave total (over lanes l, l^16, l^32, l^48) of value 4 m + fold_pick(lane)
+__device__ __forceinline__ float fold_swap32(float a, float b) {  // lanes 0-31: a(l) + a(l+32); lanes 32-63: b(l-32) + b(l)
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_swap16(float a, float b) {  // rows 0,2: a(row) + a(row+1); rows 1,3: b(row-1) + b(row)
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ int fold_pick(int lane) {  // rows 0..3 of the wave end up with values 0, 2, 1, 3 of each group of four
+  const int g = lane >> 4;
+  return ((g & 1) << 1) | (g >> 1);
+}
+template <int NQ>
+__device__ __forceinline__ void fold_rows(const float (&v)[4 * NQ], float (&w)[NQ]) {
+#pragma unroll
+  for (int m = 0; m < NQ; ++m) {
+    const float u0 = fold_swap32(v[4 * m], v[4 * m + 1]);      // rows 0,1: value 4m (rows r, r+2 added); rows 2,3: value 4m+1
+    const float u1 = fold_swap32(v[4 * m + 2], v[4 * m + 3]);  // rows 0,1: value 4m+2;                  rows 2,3: value 4m+3
+    w[m] = fold_swap16(u0, u1);                                // rows 0..3: totals of 4m, 4m+2, 4m+1, 4m+3
+  }
+}
+
 __device__ __forceinline__ void row_to_byx(int m, int Ho, int Wo, int& b, int& y, int& x) {
   x = m % Wo;
   const int t = m / Wo;

@@ -427,6 +427,9 @@ struct Builder {
   // -------------------------------------------------------------------------------- op emission
   bool leaf_scope = false;  // ops emitted now feed only parameter gradients (stem / raw-input branches)
   const bool front_matz = getenv("DMM_NO_FRONT_MATZ") == nullptr;  // A/B knob
+  // which multi-consumer gradients are materialised (q + r*y applied once by applycorr) instead of corrected by every consumer's
+  // prologue: 1 the decoder's conv_reduce outputs, 2 the last ConvTranspose's output, 4 refine0's output (A/B knob)
+  const int matz_mask = getenv("DMM_MATZ_MASK") ? atoi(getenv("DMM_MATZ_MASK")) : 7;
   Op& push(int kind) {
     ops->emplace_back();
     ops->back().kind = kind;
@@ -986,7 +989,7 @@ struct Builder {
       if (I.cw != nin) throw std::runtime_error("decoder width mismatch");
       const int n0 = new_bn(p + ".norm0", nin);
       bn_range(n0, inb, 0, 0, nin);
-      const int Rb = new_buf(I.B, I.H, I.W, nf, true, true, /*matz=*/true);
+      const int Rb = new_buf(I.B, I.H, I.W, nf, true, true, /*matz=*/(matz_mask & 1) != 0);
       {
         ConvRec& c = new_conv(p + ".conv_reduce.weight", false, nf, nin, 1, 1, 0);
         set_seg(c, 0, inb, 0, nin, 0, G_PLAIN, 1, n0, 0, DG_FLIP);
@@ -998,7 +1001,7 @@ struct Builder {
       bn_range(n1, Rb, 0, 0, nf);
       int ob;
       if (j < g.nb - 1) ob = X[g.nb - 2 - j];
-      else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true, /*matz=*/true);
+      else ob = U = new_buf(I.B, 2 * I.H, 2 * I.W, nf, true, true, /*matz=*/(matz_mask & 2) != 0);
       if (bufs[ob].H != 2 * I.H) throw std::runtime_error("decoder size mismatch");
       if (j < g.nb - 1 && nf % 8 == 0) bufs[ob].front = nf;
       {
@@ -1015,7 +1018,7 @@ struct Builder {
     const int hn0 = new_bn("dec_out_to_heat_maps.norm0", nfl + raw);
     bn_range(hn0, U, 0, 0, nfl, 4.0);
     bn_range(hn0, inH, 0, nfl, raw, 1.0, false);
-    const int YR = new_buf(B, H, Wd, nfl / 2, true, true, /*matz=*/true);
+    const int YR = new_buf(B, H, Wd, nfl / 2, true, true, /*matz=*/(matz_mask & 4) != 0);
     {
       ConvRec& c = new_conv("dec_out_to_heat_maps.refine0.weight", false, nfl / 2, nfl + raw, 3, 3, 1);
       // The decoder part of the input is a nearest-x2 upsample, so the conv is evaluated per output parity (e,f) on the

@@ -180,4 +180,69 @@ hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int nde
 hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
                          hipStream_t st);
 
+#if defined(__HIPCC__)
+// ---- the finalize steps, per channel: bodies of bn_finalize_kernel / bn_bwd_finalize_kernel ----
+// COH: the sums were added by OTHER workgroups of the running launch (float atomics execute at the memory side and leave nothing in
+// any L2; the loads bypass this CU's L1: agent-scope relaxed atomic loads = global_load ... sc1).  Only the round-3 experiment that ran
+// the steps as the tail of the producing launch used it (profiles/r03/ablations.txt: 0.8 ms SLOWER per step than launches of their own).
+template <bool COH>
+__device__ __forceinline__ double stat_load(const double* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+template <bool COH>
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeArgs& a, int c) {
+  float mean, var;
+  if (a.training) {
+    double su = stat_load<COH>(a.sum + c), sq = stat_load<COH>(a.sq + c);
+    if (a.stat_stride)
+      for (int k = 1; k < STAT_REPS; ++k) { su += stat_load<COH>(a.sum + c + (size_t)k * a.stat_stride); sq += stat_load<COH>(a.sq + c + (size_t)k * a.stat_stride); }
+    const double m = su / a.count;
+    double v = sq / a.count - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m;
+    var = (float)v;
+    const double unb = a.count_unbiased > 1 ? v * (a.count_unbiased / (a.count_unbiased - 1.0)) : v;
+    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+  } else {
+    mean = a.running_mean[c];
+    var = a.running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + a.eps);
+  const float s = a.gamma[c] * invstd;
+  a.scale[c] = s;
+  a.shift[c] = a.beta[c] - mean * s;
+  a.mean[c] = mean;
+  a.invstd[c] = invstd;
+}
+
+template <bool COH>
+__device__ __forceinline__ void bn_bwd_finalize_channel(const BnBwdFinalizeArgs& a, int c) {
+  double S1 = stat_load<COH>(a.red1 + c), S2 = stat_load<COH>(a.red2 + c);
+  if (a.stat_stride)
+    for (int k = 1; k < STAT_REPS; ++k) { S1 += stat_load<COH>(a.red1 + c + (size_t)k * a.stat_stride); S2 += stat_load<COH>(a.red2 + c + (size_t)k * a.stat_stride); }
+  const double mu = a.mean[c], is = a.invstd[c];
+  const double dotp = S2;  // sum dz * xhat, reduced in centred form by the producing kernel
+  a.dgamma[c] = (float)(dotp * a.grad_scale);
+  a.dbeta[c] = (float)(S1 * a.grad_scale);
+  if (a.qd != nullptr) {
+    const double s = a.scale[c];
+    const double c1 = S1 / a.count, c2 = dotp / a.count;
+    // contribution of this consumer to d/dx:  s*dz (stored by the dgrad epilogue)  - s*c1 - s*c2*(x-mu)*is.
+    // Accumulated in fp64 over all consumers of the channel (they cancel heavily inside dense blocks) and handed to
+    // the gathers as a two-float split: a rounding error here would be a coherent per-channel gradient offset.
+    const double q = a.qd[c] + (-s * c1 + s * c2 * mu * is);
+    const double r = a.rd[c] + (-s * c2 * is);
+    a.qd[c] = q;
+    a.rd[c] = r;
+    const float qh = (float)q, rh = (float)r;
+    a.q[c] = qh; a.ql[c] = (float)(q - (double)qh);
+    a.r[c] = rh; a.rl[c] = (float)(r - (double)rh);
+  }
+}
+
+#endif
+
 }  // namespace dmm

@@ -73,30 +73,7 @@ hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  float mean, var;
-  if (a.training) {
-    double su = a.sum[c], sq = a.sq[c];
-    if (a.stat_stride)
-      for (int k = 1; k < STAT_REPS; ++k) { su += a.sum[c + (size_t)k * a.stat_stride]; sq += a.sq[c + (size_t)k * a.stat_stride]; }
-    const double m = su / a.count;
-    double v = sq / a.count - m * m;
-    if (v < 0) v = 0;
-    mean = (float)m;
-    var = (float)v;
-    const double unb = a.count_unbiased > 1 ? v * (a.count_unbiased / (a.count_unbiased - 1.0)) : v;
-    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
-  } else {
-    mean = a.running_mean[c];
-    var = a.running_var[c];
-  }
-  const float invstd = 1.0f / sqrtf(var + a.eps);
-  const float s = a.gamma[c] * invstd;
-  a.scale[c] = s;
-  a.shift[c] = a.beta[c] - mean * s;
-  a.mean[c] = mean;
-  a.invstd[c] = invstd;
+  if (c < a.C) bn_finalize_channel<false>(a, c);
 }
 
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
@@ -106,28 +83,7 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
 
 __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  double S1 = a.red1[c], S2 = a.red2[c];
-  if (a.stat_stride)
-    for (int k = 1; k < STAT_REPS; ++k) { S1 += a.red1[c + (size_t)k * a.stat_stride]; S2 += a.red2[c + (size_t)k * a.stat_stride]; }
-  const double mu = a.mean[c], is = a.invstd[c];
-  const double dotp = S2;  // sum dz * xhat, reduced in centred form by the producing kernel
-  a.dgamma[c] = (float)(dotp * a.grad_scale);
-  a.dbeta[c] = (float)(S1 * a.grad_scale);
-  if (a.qd != nullptr) {
-    const double s = a.scale[c];
-    const double c1 = S1 / a.count, c2 = dotp / a.count;
-    // contribution of this consumer to d/dx:  s*dz (stored by the dgrad epilogue)  - s*c1 - s*c2*(x-mu)*is.
-    // Accumulated in fp64 over all consumers of the channel (they cancel heavily inside dense blocks) and handed to
-    // the gathers as a two-float split: a rounding error here would be a coherent per-channel gradient offset.
-    const double q = a.qd[c] + (-s * c1 + s * c2 * mu * is);
-    const double r = a.rd[c] + (-s * c2 * is);
-    a.qd[c] = q;
-    a.rd[c] = r;
-    const float qh = (float)q, rh = (float)r;
-    a.q[c] = qh; a.ql[c] = (float)(q - (double)qh);
-    a.r[c] = rh; a.rl[c] = (float)(r - (double)rh);
-  }
+  if (c < a.C) bn_bwd_finalize_channel<false>(a, c);
 }
 
 hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st) {
