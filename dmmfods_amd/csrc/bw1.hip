@@ -305,20 +305,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     }
     // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column (lane swaps: every lane ends
     // up with 4 of the 16 finished wave totals), then fp64 in LDS - 4 LDS atomics per lane instead of 16 on a quarter of the lanes
-    {
-      float v[2 * SLOT], w[SLOT / 2];
-#pragma unroll
-      for (int e = 0; e < SLOT; ++e) { v[e] = s1[e]; v[SLOT + e] = s2[e]; }
-      fold_rows<SLOT / 2>(v, w);
-      if (cvalid) {
-        const int pick = fold_pick(lane);
-#pragma unroll
-        for (int m = 0; m < SLOT / 2; ++m) {  // value 4 m + pick: m < 2 -> s1[4 m + pick], else s2[4 (m - 2) + pick]
-          const int vi = 4 * m + pick;
-          atomicAdd(&red[(m >= SLOT / 4 ? B1_CT : 0) + cs * SLOT + (vi & (SLOT - 1))], (double)w[m]);
-        }
-      }
-    }
+    fold_to_lds<16, SLOT, B1_CT>(s1, s2, red, cs, cvalid, lane);
     }  // (epilogue)
     __syncthreads();  // staging read: the next tile's images may be written
   }

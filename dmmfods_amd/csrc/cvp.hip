@@ -472,21 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
     }
     *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
   }
-#pragma unroll
-  for (int i = 0; i < SLOT; ++i) {
-#pragma unroll
-    for (int d = NCV; d < 64; d <<= 1) {
-      s1[i] += __shfl_xor(s1[i], d, 64);
-      s2[i] += __shfl_xor(s2[i], d, 64);
-    }
-  }
-  if (colvalid && lane < NCV) {
-#pragma unroll
-    for (int i = 0; i < SLOT; ++i) {
-      atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
-      atomicAdd(&red[BN + cv * SLOT + i], (double)s2[i]);
-    }
-  }
+  fold_to_lds<NCV, SLOT, BN>(s1, s2, red, cv, colvalid, lane);
   __syncthreads();
   if (tid < BN && n0 + tid < a.N) {
     const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;

@@ -396,15 +396,17 @@ __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSl
 // finished wave total per group of four values instead of all of them in every lane.
 //   in:  v[0 .. 4 NQ)   this lane's partials
 //   out: w[m], m < NQ = the wave total (over lanes l, l^16, l^32, l^48) of value 4 m + fold_pick(lane)
+// (Inline asm with its own padding, not __builtin_amdgcn_permlane{32,16}_swap: with the builtin, hipcc / ROCm 7.2 scheduled the scalar
+// fp32 igemm epilogue so that ONE lane of a wave folded a stale value - tests/test_kernels_gpu.py [*-scalar-fp32] - while the MFMA
+// variants of the same source were right.  The swaps need 2 wait states behind a VALU write of either operand (cdna_hip_programming.md
+// T21); the pads sit inside the asm strings, on both sides, where no scheduler can move them.)
 __device__ __forceinline__ float fold_swap32(float a, float b) {  // lanes 0-31: a(l) + a(l+32); lanes 32-63: b(l-32) + b(l)
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 __device__ __forceinline__ float fold_swap16(float a, float b) {  // rows 0,2: a(row) + a(row+1); rows 1,3: b(row-1) + b(row)
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 __device__ __forceinline__ int fold_pick(int lane) {  // rows 0..3 of the wave end up with values 0, 2, 1, 3 of each group of four
   const int g = lane >> 4;
@@ -417,6 +419,50 @@ __device__ __forceinline__ void fold_rows(const float (&v)[4 * NQ], float (&w)[N
     const float u0 = fold_swap32(v[4 * m], v[4 * m + 1]);      // rows 0,1: value 4m (rows r, r+2 added); rows 2,3: value 4m+1
     const float u1 = fold_swap32(v[4 * m + 2], v[4 * m + 3]);  // rows 0,1: value 4m+2;                  rows 2,3: value 4m+3
     w[m] = fold_swap16(u0, u1);                                // rows 0..3: totals of 4m, 4m+2, 4m+1, 4m+3
+  }
+}
+
+// Epilogue reductions of the convolution kernels: every lane holds partials s1[SLOT] | s2[SLOT] of its slot column cv = lane % NCV
+// (NCV = 4, 8, 16 or 32 columns; the lanes l, l + NCV, ... of a wave share a column).  Adds the wave totals to the workgroup's fp64
+// accumulators red[0 .. BN) (s1) and red[BN .. 2 BN) (s2) in LDS.  Lanes inside a 16-lane row are folded by DPP row rotations
+// (one v_add_f32 each), the rows by fold_rows: every lane is left with a quarter of the column's totals and issues SLOT/2 LDS atomics
+// (a __shfl_xor per step and value, then 2 SLOT atomics on 1/4 .. 1/16 of the lanes before round 3).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+template <int NCV, int SLOT, int BN>
+__device__ __forceinline__ void fold_to_lds(const float (&s1)[SLOT], const float (&s2)[SLOT], double* red, int cv, bool colvalid, int lane) {
+  static_assert((NCV == 4 || NCV == 8 || NCV == 16 || NCV == 32) && SLOT % 4 == 0, "slot columns per wave");
+  float v[2 * SLOT];
+#pragma unroll
+  for (int e = 0; e < SLOT; ++e) { v[e] = s1[e]; v[SLOT + e] = s2[e]; }
+  if constexpr (NCV == 32) {  // two lanes per column: one swap folds a pair of values
+#pragma unroll
+    for (int k = 0; k < SLOT; ++k) {
+      const float t = fold_swap32(v[2 * k], v[2 * k + 1]);  // lanes 0-31: value 2k, lanes 32-63: value 2k+1
+      const int vi = 2 * k + (lane >> 5);
+      if (colvalid) atomicAdd(&red[(vi >= SLOT ? BN : 0) + cv * SLOT + (vi & (SLOT - 1))], (double)t);
+    }
+  } else {
+    if constexpr (NCV <= 8) {
+#pragma unroll
+      for (int e = 0; e < 2 * SLOT; ++e) v[e] = dpp_add<0x128>(v[e]);  // row_ror:8
+    }
+    if constexpr (NCV <= 4) {
+#pragma unroll
+      for (int e = 0; e < 2 * SLOT; ++e) v[e] = dpp_add<0x124>(v[e]);  // row_ror:4
+    }
+    float w[SLOT / 2];
+    fold_rows<SLOT / 2>(v, w);
+    if (colvalid && (lane & 15) < NCV) {
+      const int pick = fold_pick(lane);
+#pragma unroll
+      for (int m = 0; m < SLOT / 2; ++m) {
+        const int vi = 4 * m + pick;
+        atomicAdd(&red[(vi >= SLOT ? BN : 0) + cv * SLOT + (vi & (SLOT - 1))], (double)w[m]);
+      }
+    }
   }
 }
 
