@@ -58,7 +58,7 @@ __device__ __forceinline__ typename TT<T>::vec b1_frag(const b1_u32x2& lo, const
 
 // PQ = prologue of G: 0 none (materialised gradient), 2 effective gradient.  ACC = the gradient of x is accumulated (an earlier
 // consumer of the block buffer has already written it).
-template <typename T, int PQ, bool ACC_>
+template <typename T, int PQ, bool ACC_, bool PART>
 __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   constexpr bool ACC = ACC_ && !(B1_DBG & 32);
   static_assert(sizeof(T) == 2, "16-bit storage");
@@ -317,7 +317,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     atomic_add_f64(a.red2 + rep + c0 + tid, red[B1_CT + tid]);
   }
   const int c = c0 + 32 * wave + r;
-  if (!(B1_DBG & 1) && c < g.wC) {
+  if constexpr (PART) {  // this workgroup's slot, in the layout of the dpack slice (whole slot: the reduction reads all of it)
+    float* slot = g.part + ((size_t)split * g.nct + ct) * B1_SLOT_FLOATS + (size_t)wave * (B1_NB * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h;
+        slot[n * 32 + r] = accw[j][i];
+      }
+  } else if (!(B1_DBG & 1) && c < g.wC) {
     const size_t chunk = (size_t)(c0 / 32 + wave);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -341,9 +350,9 @@ static bool g_bw1 = getenv("DMM_NO_BW1") == nullptr;
 void bw1_set_enabled(bool on) { g_bw1 = on; }
 bool bw1_enabled() { return g_bw1; }
 
-template <typename T, int PQ, bool ACC>
+template <typename T, int PQ, bool ACC, bool PART>
 static hipError_t launch_bw1_t(const Bw1Args& g, int nwg, hipStream_t st) {
-  auto kern = bw1_kernel<T, PQ, ACC>;
+  auto kern = bw1_kernel<T, PQ, ACC, PART>;
   static bool attr_done = false;
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
@@ -373,30 +382,85 @@ bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype) {
   return true;
 }
 
+Bw1Geom bw1_geometry(const ConvArgs& a) {
+  Bw1Geom q;
+  q.nct = (a.N + B1_CT - 1) / B1_CT;
+  q.ntiles = (a.M + B1_TM - 1) / B1_TM;
+  static const int cus = [] { hipDeviceProp_t pr; int dev = 0;
+                              return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                                         ? pr.multiProcessorCount : 256; }();
+  static const int per_cu = getenv("DMM_BW1_PER_CU") ? atoi(getenv("DMM_BW1_PER_CU")) : 2;
+  // every workgroup ends with 64 KB of weight gradient to hand over and a tile is ~2 us of work: at least 4 tiles per workgroup
+  int nsplit = std::max(1, (per_cu * cus + q.nct - 1) / q.nct);
+  nsplit = std::min(nsplit, std::max(1, q.ntiles / 4));
+  q.tiles_per_wg = (q.ntiles + nsplit - 1) / nsplit;
+  q.nsplit = (q.ntiles + q.tiles_per_wg - 1) / q.tiles_per_wg;   // every row range has at least one tile
+  q.xcd_group = (q.nct > 1 && q.nsplit >= 32 && q.tiles_per_wg >= 8) ? 1 : 0;  // (measured: block 1-2 gain, block 3 loses)
+  // whole groups of 8 row ranges (one per XCD); surplus workgroups return at once
+  q.nwg = q.xcd_group ? ((q.nsplit + 7) / 8) * 8 * q.nct : q.nsplit * q.nct;
+  return q;
+}
+
+static bool g_bw1_part = getenv("DMM_NO_BW1_PART") == nullptr;
+
+static bool bw1_uses_part(const Bw1Args& g, const Bw1Geom& q) {
+  return g_bw1_part && g.part != nullptr && q.nsplit * q.nct <= g.part_slots && q.nsplit > 1;
+}
+
 hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
   Bw1Args g = g0;
   const ConvArgs& a = g.c;
   if (a.M <= 0) return hipSuccess;
-  g.nct = (a.N + B1_CT - 1) / B1_CT;
-  g.ntiles = (a.M + B1_TM - 1) / B1_TM;
-  static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
-                              return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const int per_cu = getenv("DMM_BW1_PER_CU") ? atoi(getenv("DMM_BW1_PER_CU")) : 2;
-  // every workgroup ends with 64 KB of fp32 atomics and a tile is ~2 us of work: at least 4 tiles per workgroup
-  int nsplit = std::max(1, (per_cu * cus + g.nct - 1) / g.nct);
-  nsplit = std::min(nsplit, std::max(1, g.ntiles / 4));
-  g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
-  nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
-  g.xcd_group = (g.nct > 1 && nsplit >= 32 && g.tiles_per_wg >= 8) ? 1 : 0;  // (measured: block 1-2 gain, block 3 loses)
-  const int nwg = g.xcd_group ? ((nsplit + 7) / 8) * 8 * g.nct : nsplit * g.nct;  // whole groups of 8 row ranges (one per XCD); surplus workgroups return at once
+  const Bw1Geom q = bw1_geometry(a);
+  g.nct = q.nct; g.ntiles = q.ntiles; g.tiles_per_wg = q.tiles_per_wg; g.xcd_group = q.xcd_group; g.nsplit = q.nsplit;
+  const int nwg = q.nwg;
   const int pq = a.seg[0].q ? 2 : 0;
   const bool acc = a.accumulate != 0;
-  if (dtype == DT_F16) {
-    if (pq) return acc ? launch_bw1_t<f16, 2, true>(g, nwg, st) : launch_bw1_t<f16, 2, false>(g, nwg, st);
-    return acc ? launch_bw1_t<f16, 0, true>(g, nwg, st) : launch_bw1_t<f16, 0, false>(g, nwg, st);
+  const bool part = bw1_uses_part(g, q);
+#define B1_GO(T) \
+  (part ? (pq ? (acc ? launch_bw1_t<T, 2, true, true>(g, nwg, st) : launch_bw1_t<T, 2, false, true>(g, nwg, st))     \
+              : (acc ? launch_bw1_t<T, 0, true, true>(g, nwg, st) : launch_bw1_t<T, 0, false, true>(g, nwg, st)))    \
+        : (pq ? (acc ? launch_bw1_t<T, 2, true, false>(g, nwg, st) : launch_bw1_t<T, 2, false, false>(g, nwg, st))   \
+              : (acc ? launch_bw1_t<T, 0, true, false>(g, nwg, st) : launch_bw1_t<T, 0, false, false>(g, nwg, st))))
+  if (dtype == DT_F16) return B1_GO(f16);
+  return B1_GO(bf16);
+#undef B1_GO
+}
+
+// dpack slice = sum over the row ranges of the slots; the slots hold zeros for padding channels, which dpack has rows for as well
+// (chunks of 32 channels) up to ceil(wC / 32) chunks: a thread owns 4 consecutive floats of a slice.
+__global__ __launch_bounds__(256) void bw1_reduce_kernel(const float* __restrict__ part, float* __restrict__ dpack, int nct, int nsplit, int nfloats) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // float index into the packed gradient (all slices)
+  if (e >= nct * B1_SLOT_FLOATS) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* p = part + e;  // slot (0, ct) starts at ct * B1_SLOT_FLOATS: the slices of one row range are contiguous
+  const size_t pitch = (size_t)nct * B1_SLOT_FLOATS;
+  int k = 0;
+  for (; k + 16 <= nsplit; k += 16) {  // sixteen independent 16-byte loads in flight per thread: the launch has few workgroups
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(p + (size_t)(k + u) * pitch));
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
   }
-  if (pq) return acc ? launch_bw1_t<bf16, 2, true>(g, nwg, st) : launch_bw1_t<bf16, 2, false>(g, nwg, st);
-  return acc ? launch_bw1_t<bf16, 0, true>(g, nwg, st) : launch_bw1_t<bf16, 0, false>(g, nwg, st);
+  for (; k + 4 <= nsplit; k += 4) {
+    const f32x4 v0 = *(const f32x4*)(p + (size_t)k * pitch), v1 = *(const f32x4*)(p + (size_t)(k + 1) * pitch);
+    const f32x4 v2 = *(const f32x4*)(p + (size_t)(k + 2) * pitch), v3 = *(const f32x4*)(p + (size_t)(k + 3) * pitch);
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; k < nsplit; ++k) s += *(const f32x4*)(p + (size_t)k * pitch);
+  if (e < nfloats) *(f32x4*)(dpack + e) = s;
+}
+
+hipError_t launch_bw1_reduce(const Bw1Args& g, hipStream_t st) {
+  const ConvArgs& a = g.c;
+  if (a.M <= 0) return hipSuccess;
+  const Bw1Geom q = bw1_geometry(a);
+  if (!bw1_uses_part(g, q)) return hipSuccess;  // the fused launch added into dpack itself
+  const int nfloats = ((g.wC + 31) / 32) * g.dNpad * 32;  // size of dpack
+  const int nthreads = q.nct * B1_SLOT_FLOATS / 4;
+  hipLaunchKernelGGL(bw1_reduce_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, st, g.part, g.dpack, q.nct, q.nsplit, nfloats);
+  return hipGetLastError();
 }
 
 }  // namespace dmm

@@ -212,6 +212,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_IGEMM: e = launch_igemm(o.c, dt, o.epi, mfma, lst, o.impl); break;
       case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst, o.impl); break;
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
+      case OP_BW1RED: e = launch_bw1_reduce(o.b1, lst); break;
       case OP_JOIN: join(); break;  // the main stream waits for what the side stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
@@ -830,7 +831,17 @@ int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void
   wa.dpack = (float*)packs[0].dpack;
   if (!bw1_eligible(wa, b.c, d->dtype)) return fail(DMM_ERR_INVALID, "not a pair bw1.hip fuses (16-bit storage, 128 output channels, Cin % 32 == 0)");
   b.dpack = wa.dpack; b.dNpad = wa.Npad; b.wC = wa.seg[0].C;
-  HIPCHK(launch_bw1(b, d->dtype, st));
+  {  // the production form: per-workgroup slots + the reduction launch (stream-ordered scratch of this call)
+    const Bw1Geom q = bw1_geometry(b.c);
+    b.part_slots = q.nsplit * q.nct;
+    void* part = nullptr;
+    HIPCHK(hipMallocAsync(&part, (size_t)b.part_slots * B1_SLOT_FLOATS * sizeof(float), st));
+    b.part = (float*)part;
+    const hipError_t e1 = launch_bw1(b, d->dtype, st);
+    const hipError_t e2 = e1 == hipSuccess ? launch_bw1_reduce(b, st) : e1;
+    hipFreeAsync(part, st);
+    HIPCHK(e2);
+  }
   const size_t wn = (size_t)d->Cin * d->Cout;
   HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
   HIPCHK(launch_unpack(dd, dp, (int)packs.size(), total_rows, d->dtype, 1.0f, st));

@@ -349,9 +349,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     // one LDS word per column and wave, fp64 from there on (per-lane partials cover 16 rows: fp32 is exact enough, see igemm.hip)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      ps1[t] += __shfl_xor(ps1[t], 32, 64);
-      ps2[t] += __shfl_xor(ps2[t], 32, 64);
-      if (h == 0) { wpart[(wave * 2 + 0) * BN + 32 * t + r] = ps1[t]; wpart[(wave * 2 + 1) * BN + 32 * t + r] = ps2[t]; }
+      wpart[(wave * 2 + h) * BN + 32 * t + r] = fold_swap32(ps1[t], ps2[t]);  // lane half 0: the sum, half 1: the sum of squares
     }
   }
   __syncthreads();

@@ -396,17 +396,16 @@ __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSl
 // finished wave total per group of four values instead of all of them in every lane.
 //   in:  v[0 .. 4 NQ)   this lane's partials
 //   out: w[m], m < NQ = the wave total (over lanes l, l^16, l^32, l^48) of value 4 m + fold_pick(lane)
-// (Inline asm with its own padding, not __builtin_amdgcn_permlane{32,16}_swap: with the builtin, hipcc / ROCm 7.2 scheduled the scalar
-// fp32 igemm epilogue so that ONE lane of a wave folded a stale value - tests/test_kernels_gpu.py [*-scalar-fp32] - while the MFMA
-// variants of the same source were right.  The swaps need 2 wait states behind a VALU write of either operand (cdna_hip_programming.md
-// T21); the pads sit inside the asm strings, on both sides, where no scheduler can move them.)
+// (The builtins: hipcc pads the 2 wait states the swaps need behind a VALU write of either operand itself - cdna_hip_programming.md T21.)
 __device__ __forceinline__ float fold_swap32(float a, float b) {  // lanes 0-31: a(l) + a(l+32); lanes 32-63: b(l-32) + b(l)
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float fold_swap16(float a, float b) {  // rows 0,2: a(row) + a(row+1); rows 1,3: b(row-1) + b(row)
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ int fold_pick(int lane) {  // rows 0..3 of the wave end up with values 0, 2, 1, 3 of each group of four
   const int g = lane >> 4;

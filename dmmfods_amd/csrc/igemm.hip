@@ -459,9 +459,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
           if (ACCSTAT && rok[i]) { const float f = to_f32(v); ps1 += f; ps2 = fmaf(f, f, ps2); }
         }
         if (ACCSTAT) {
-          ps1 += __shfl_xor(ps1, 32, 64);
-          ps2 += __shfl_xor(ps2, 32, 64);
-          if (h == 0) { wpart[(wave * 2 + 0) * BN + 32 * t + r] = ps1; wpart[(wave * 2 + 1) * BN + 32 * t + r] = ps2; }
+          wpart[(wave * 2 + h) * BN + 32 * t + r] = fold_swap32(ps1, ps2);  // lane half 0: the sum, half 1: the sum of squares
         }
       }
     } else {

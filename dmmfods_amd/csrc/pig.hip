@@ -191,9 +191,7 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
           Cs[row * PG_PITCH + 32 * t + r] = v;
           if (m0 + row < a.M) { const float f = to_f32(v); ps1 += f; ps2 = fmaf(f, f, ps2); }  // sums of the values AS STORED
         }
-        ps1 += __shfl_xor(ps1, 32, 64);
-        ps2 += __shfl_xor(ps2, 32, 64);
-        if (h == 0) { wpart[(wave * 2 + 0) * BN + 32 * t + r] = ps1; wpart[(wave * 2 + 1) * BN + 32 * t + r] = ps2; }
+        wpart[(wave * 2 + h) * BN + 32 * t + r] = fold_swap32(ps1, ps2);  // lane half 0: the sum, half 1: the sum of squares
       }
     }
     __syncthreads();

@@ -749,16 +749,34 @@ struct Builder {
       if (pending_w) {
         pending_w = false;
         Op dgrad_op = ops->back();
+        // slots for the weight-gradient partials of the fused launch (pointwise.h: Bw1Args::part).  Reserved by the shape of the pair
+        // alone - the sizing pass and the bound pass must take the same bytes, and bw1_eligible looks at pointers
+        float* part = nullptr;
+        int part_slots = 0;
+        if (!raw && dtype != DT_F32 && c.R == 1 && c.S == 1 && c.N == 128 && c.nseg == 1) {
+          const Bw1Geom q = bw1_geometry(dgrad_op.c);
+          part_slots = q.nsplit * q.nct;
+          part = wptr<float>((size_t)part_slots * B1_SLOT_FLOATS);
+        }
         if (!raw && bw1_eligible(saved_w.w, dgrad_op.c, dtype)) {
           Op& f = ops->back();
           f.kind = OP_BW1;
           f.b1.dpack = saved_w.w.dpack;
           f.b1.dNpad = saved_w.w.Npad;
           f.b1.wC = saved_w.w.seg[0].C;
-          f.b1.nct = f.b1.ntiles = f.b1.tiles_per_wg = f.b1.xcd_group = 0;
+          f.b1.part = part;
+          f.b1.part_slots = part_slots;
+          f.b1.nct = f.b1.ntiles = f.b1.tiles_per_wg = f.b1.xcd_group = f.b1.nsplit = 0;
           char cb[32];
           // the pair's traffic with every operand read once: the data gradient's bytes + the packed weight gradient
           tag(f, ncls("bw1", f.c.Npad, cb), short_name(c.wname), dgrad_op.flops + saved_w.flops, dgrad_op.bytes + w_bytes(c) * 4.0 / esz);
+          if (part != nullptr) {  // the slots are added up beside the data-gradient chain (weight-gradient stream)
+            const Bw1Args b1 = f.b1;
+            Op& rop = push(OP_BW1RED);
+            rop.leaf = 1;
+            rop.b1 = b1;
+            tag(rop, "bw1.reduce", short_name(c.wname), 0, ((double)part_slots + b1.nct) * B1_SLOT_FLOATS * 4.0);
+          }
           conv_grad_done(c);
         } else {  // not this time: weight gradient, bucket bookkeeping, data gradient - in the original order
           ops->pop_back();

@@ -33,7 +33,7 @@ void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK);
 void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK);
 
 enum OpKind { OP_MEMSET = 0, OP_CONVERT, OP_IGEMM, OP_WGRAD, OP_BNFIN, OP_BNBWD, OP_POOL, OP_POOLBWD, OP_BCE, OP_PACK, OP_UNPACK,
-              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN };
+              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN, OP_BW1RED };
 
 struct MemsetArgs { void* p; size_t bytes; };
 struct CopyArgs { void* dst; const void* src; size_t bytes; };

@@ -147,10 +147,20 @@ struct Bw1Args {
   ConvArgs c;
   float* dpack;       // fp32 packed weight gradient [chunk = c / 32][dNpad][32]
   int dNpad, wC;      // its row pitch (128) and the real number of input channels
-  int nct, ntiles, tiles_per_wg, xcd_group;  // (filled by the launcher)
+  // Weight-gradient partials (nullable).  Every workgroup ends with a 64 KB slice of the weight gradient in registers.  Added to
+  // dpack with fp32 atomics that is 33 MB per launch at the atomics' 1.3 TB/s - 0.9 ms of the step on the data-gradient chain.
+  // With `part` each workgroup STORES its slice to slot (row range * nct + channel slice) (plain stores: 6 TB/s) and a second
+  // launch (launch_bw1_reduce, on the weight-gradient stream) adds the slots up into dpack.
+  float* part;
+  int part_slots;     // capacity of `part` in 64 KB slots
+  int nct, ntiles, tiles_per_wg, xcd_group, nsplit;  // (filled by the launcher)
 };
+struct Bw1Geom { int nct, ntiles, tiles_per_wg, nsplit, xcd_group, nwg; };
+Bw1Geom bw1_geometry(const ConvArgs& a);   // how launch_bw1 splits the launch (device-dependent: compute units)
+constexpr int B1_SLOT_FLOATS = 4 * 128 * 32;  // one workgroup's slice: 4 chunks of 32 input channels x 128 bottleneck channels
 bool bw1_eligible(const WgradArgs& w, const ConvArgs& d, int dtype);
 hipError_t launch_bw1(const Bw1Args& g, int dtype, hipStream_t st);
+hipError_t launch_bw1_reduce(const Bw1Args& g, hipStream_t st);  // dpack = sum of the slots (no-op without `part`)
 hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStream_t st, int impl = IMPL_AUTO);
 hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int impl = IMPL_AUTO);
 int igemm_pick(const ConvArgs& a, int dtype, int epi, bool mfma);   // the family (enum Impl) that would run the launch now
