@@ -976,11 +976,13 @@ struct Builder {
         transition("stream_2_features.transition" + std::to_string(b + 1), X2[b], 0, g.cout[b], last ? F : X2[b + 1],
                    last ? g.cin[cbb - 1] : 0);
       }
+      s2_recs = recs.size();
     }
     stem("features", in1, g.net_in, X[0], base[0]);
     for (int b = 0; b < g.nb; ++b) {
       if (g.fusion == 2 && b == cbb - 1) {
         const int C = g.cin[b];
+        concat_rec = recs.size();
         const int n = new_bn("concat_module.norm", 2 * C);
         bn_range(n, F, 0, 0, 2 * C);
         ConvRec& c = new_conv("concat_module.conv.weight", false, C, 2 * C, 1, 1, 0);
@@ -1108,6 +1110,22 @@ struct Builder {
     o.pk.total_rows = total_rows;
     o.pk.grad_scale = 1.0f / d.loss_scale;
     tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
+  }
+  // Mid fusion: the second stream's encoder (records [0, s2_recs)) shares nothing with the first stream's until the concat module
+  // (record concat_rec) reads both.  Its forward launches go to the side stream beside the first stream's: each chain alone leaves
+  // the chip idle between its dependent launches (finalize steps, small late-block grids).
+  size_t s2_recs = 0, concat_rec = 0;
+  const bool s2_overlap = getenv("DMM_NO_S2_OVERLAP") == nullptr;  // A/B knob
+  void emit_forward_records() {
+    for (size_t ri = 0; ri < recs.size(); ++ri) {
+      const Rec& r = recs[ri];
+      const bool beside = g.fusion == 2 && s2_overlap && s2_recs > 0;
+      if (beside && ri == concat_rec) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
+      leaf_scope = beside && ri < s2_recs;
+      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
+      leaf_scope = false;
+      if (ri == 0) emit_pack_join();
+    }
   }
   void emit_pack_join() {
     if (pack_split > 0) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
@@ -1252,11 +1270,7 @@ struct Builder {
     emit_pack_op(OP_PACK);
     P.convert_ops_train.clear();
     emit_convert(P.convert_ops_train);
-    for (size_t ri = 0; ri < recs.size(); ++ri) {
-      const Rec& r = recs[ri];
-      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
-      if (ri == 0) emit_pack_join();
-    }
+    emit_forward_records();
     // ---- eval forward ----
     ops = sizing ? &dummy : &P.fwd_eval;
     ops->clear();
@@ -1264,11 +1278,7 @@ struct Builder {
     emit_pack_op(OP_PACK);
     P.convert_ops_eval.clear();
     emit_convert(P.convert_ops_eval);
-    for (size_t ri = 0; ri < recs.size(); ++ri) {
-      const Rec& r = recs[ri];
-      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
-      if (ri == 0) emit_pack_join();
-    }
+    emit_forward_records();
     // ---- loss + backward ----
     ops = sizing ? &dummy : &P.bwd;
     ops->clear();
