@@ -22,6 +22,9 @@
 #include "common.h"
 #include "gather.h"
 
+#ifndef WG3_DBG
+#define WG3_DBG 0  // timing experiments only (tools/build_variant.sh): 1 no atomics at the end of the walk
+#endif
 namespace dmm {
 
 constexpr int W3_TH = 8, W3_TW = 16, W3_HH = 10, W3_HW = 18;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void wg3_kernel(const Wg3Args g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-      atomic_add_f32(a.dpack + ((size_t)t * a.Npad + c) * 32 + r, acc[t][i]);
+      if (!(WG3_DBG & 1) || acc[t][i] == 1.2345e33f) atomic_add_f32(a.dpack + ((size_t)t * a.Npad + c) * 32 + r, acc[t][i]);
     }
 }
 
