@@ -26,7 +26,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 static bool g_overlap_wgrad = getenv("DMM_NO_OVERLAP") == nullptr;
-static bool g_graph = getenv("DMM_GRAPH") != nullptr;  // off by default: see launch_list
+static int g_graph = getenv("DMM_GRAPH") ? std::max(1, atoi(getenv("DMM_GRAPH"))) : 0;  // off by default: see launch_list (1: both lists, 2: the forward list only)
 static unsigned long long g_option_epoch = 1;  // bumped by every dmm_set_option: captured graphs have the options of their time baked in
 static int g_bucket_mb = getenv("DMM_GRAD_BUCKET_MB") ? atoi(getenv("DMM_GRAD_BUCKET_MB")) : 25;
 
@@ -39,7 +39,7 @@ int dmm_set_option(const char* name, int value) {
   if (!name) return fail(DMM_ERR_INVALID, "null argument");
   ++g_option_epoch;
   if (std::string(name) == "overlap_wgrad") { g_overlap_wgrad = value != 0; return DMM_OK; }
-  if (std::string(name) == "graph") { g_graph = value != 0; return DMM_OK; }
+  if (std::string(name) == "graph") { g_graph = value; return DMM_OK; }
   if (std::string(name) == "thin_logits") { dmm::thin_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "conv3") { dmm::conv3_set_enabled(value != 0); return DMM_OK; }
   if (std::string(name) == "wg3") { dmm::wg3_set_enabled(value != 0); return DMM_OK; }
@@ -275,7 +275,7 @@ static int launch_list(dmm_plan* p, int which, std::vector<Op>& ops, size_t seg_
     gc.nseen = 0;
     gc.epoch = g_option_epoch;
   }
-  const bool want = g_graph && !p->graph_failed && !profiling && !(which == 1 && p->dp_used) && seg_end > seg_begin + 8;
+  const bool want = g_graph && !(g_graph == 2 && which == 1) && !p->graph_failed && !profiling && !(which == 1 && p->dp_used) && seg_end > seg_begin + 8;
   if (!want) return run_ops(p, ops, st, which);
   if (gc.entries.empty() && gc.nseen > 0) {  // the second run of the list: capture the segment
     if (p->capture_stream == nullptr) {

@@ -68,7 +68,7 @@ typedef struct dmm_plan dmm_plan;
 
 const char* dmm_last_error(void);
 int dmm_version(void);
-/* Switches for tests and A/B timing: "graph" (1 = replay captured launch lists, see dmm_plan_num_graph_replays), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the
+/* Switches for tests and A/B timing: "graph" (1 = replay captured launch lists, 2 = the forward list only; see dmm_plan_num_graph_replays), "overlap_wgrad" (1 = weight-gradient GEMMs on a second stream beside the
  * data-gradient chain, 0 = one stream; read at every call), and the kernel families "thin_logits" (gather-once kernel for the
  * heat-map head's last convolution), "conv3" (LDS halo-tile kernels of the multi-tap convolutions), "wg3" (the growth convolution's
  * weight gradient), "wgp" (weight gradients of the parity-phase convolutions), "wg5" (of the 5x5 head / 7x7 stem convolutions),
