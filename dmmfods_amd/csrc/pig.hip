@@ -37,7 +37,7 @@ struct PigArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
+__global__ __launch_bounds__(NTHREADS, 2) void pig_kernel(const PigArgs g) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
   constexpr int SLOT = 8, BK = 32, BN = PG_BN, KS = PG_KS, NT = PG_NT;
@@ -93,38 +93,54 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
     RawSlot<T> raw[NR];
     int c;
   };
-  ARing RA;
-  size_t roff[NR];
+  // Two register sets: the loads of stage s + 2 are requested while stage s is multiplied, and the barriers of the K loop are raw
+  // s_barrier instructions behind a COUNTED wait - __syncthreads() is a workgroup-scope fence, on gfx9 an s_waitcnt vmcnt(0), which
+  // drained every prefetch twice per stage: the loads of a stage then had a fraction of one MFMA block to land, and the K-deep launches
+  // (blocks 3-4, the decoder's conv_reduce with 1.5-2 K channels) ran at one HBM latency per stage.
+  ARing RA, RB;
+  unsigned roff[NR];   // byte offsets of the cursor tile's rows (the launcher keeps the operand below 4 GiB)
   bool rv[NR];
   auto rows_of = [&](int mtile) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int m = mtile * BM + rg + RST * i;
       rv[i] = m < a.M;
-      roff[i] = (size_t)(rv[i] ? m : 0) * ld;
+      roff[i] = (unsigned)(rv[i] ? m : 0) * (unsigned)ld * (unsigned)sizeof(T);
     }
   };
-  auto issue_a = [&](int stage) {  // branch-free: clamped addresses, dropped by `state` (see igemm.hip)
-    const int gch = stage * KS + u;
+  // the issue cursor walks (tile, stage) pairs in the order they are consumed and runs ahead of the tile being multiplied
+  int cur_tile = walker, cur_stage = 0;
+  const unsigned char* abase = (const unsigned char*)sg.src;
+  auto issue_a = [&](ARing& R) {  // branch-free: clamped addresses, dropped by `state` (see igemm.hip); ALWAYS NR loads (counted waits)
+    const int gch = cur_stage * KS + u;
     const int c = gch * BK + j * SLOT;
-    const bool cv = gch < total && c < C;
+    const bool cv = gch < total && c < C && cur_tile < g.mtiles;
     const int cc = cv ? c : 0;
-    RA.c = cc;
+    R.c = cc;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      RA.raw[i].v = *(const V*)((const T*)sg.src + roff[i] + cc);
-      RA.raw[i].state = (cv && rv[i]) ? 1 : 3;
+      R.raw[i].v = *(const V*)(abase + roff[i] + (unsigned)cc * (unsigned)sizeof(T));
+      R.raw[i].state = (cv && rv[i]) ? 1 : 3;
+    }
+    if (++cur_stage == nstages) {
+      cur_stage = 0;
+      cur_tile += g.walkers;
+      rows_of(cur_tile < g.mtiles ? cur_tile : walker);
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](const ARing& R, int buf) {
     unsigned char* As = smem + buf * (PG_A_BYTES + PG_B_BYTES);
-    const SlotK<SLOT> kk = lds_slot_consts_n<SLOT, 2>(lk, C, RA.c);
+    const SlotK<SLOT> kk = lds_slot_consts_n<SLOT, 2>(lk, C, R.c);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int row = u * BM + rg + RST * i;
-      *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = finish_slot<T, 1>(2, RA.raw[i], kk);
+      *(V*)(As + row * ROWB + ((j ^ ((rg >> 2) & 3)) << 4)) = finish_slot<T, 1>(2, R.raw[i], kk);
     }
   };
+  // raw barriers: this wave's LDS traffic has returned (lgkmcnt) and all but its N youngest vector-memory operations have completed
+  auto bar_all = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto bar_keep = [&]() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NR) : "memory"); };   // the newest A request stays in flight
+  auto bar_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };                        // LDS only
   f32x16 acc[NT];
   auto mma = [&](int buf) {
     const unsigned char* As = smem + buf * (PG_A_BYTES + PG_B_BYTES);
@@ -153,7 +169,8 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
   int mtile = walker;
   rows_of(mtile);
   __syncthreads();  // constants staged
-  issue_a(0);
+  issue_a(RA);
+  issue_a(RB);
   while (true) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -161,24 +178,21 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     issue_b(0, 0);
     for (int it = 0; it < nstages; it += 2) {
-      store_a(0);
-      __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+      store_a(RA, 0);
+      if (it == 0) bar_all(); else bar_keep();  // the weight DMA of this stage has landed (it == 0: it was the newest request)
       issue_b(1, it + 1);
-      issue_a(it + 1);  // past the end: dead stage (clamped loads, dropped)
+      issue_a(RA);                              // stage it + 2 (or the next tile's: the cursor runs on)
       mma(0);
-      store_a(1);
-      __syncthreads();
-      if (it + 2 < nstages) { issue_b(0, it + 2); issue_a(it + 2); }  // (the staging below reuses the image: no DMA may be left in flight)
+      store_a(RB, 1);
+      bar_keep();
+      if (it + 2 < nstages) issue_b(0, it + 2);  // (the staging below reuses the image: no DMA may be left in flight)
+      issue_a(RB);
       mma(1);
     }
     const int m0 = mtile * BM;
     const int next = mtile + g.walkers;
     const bool more = next < g.mtiles;   // (workgroup-uniform)
-    if (more) {                           // the next tile's first stage flies under this tile's epilogue
-      rows_of(next);
-      issue_a(0);
-    }
-    __syncthreads();  // all waves done with the operand images: stage the tile over them
+    if (nstages > 0) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NR) : "memory"); }  // all waves done with the operand images (no DMA left: only the two A requests of the next tile fly on): stage the tile over them
     {
       T* Cs = (T*)smem;
 #pragma unroll
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
         wpart[(wave * 2 + h) * BN + 32 * t + r] = fold_swap32(ps1, ps2);  // lane half 0: the sum, half 1: the sum of squares
       }
     }
-    __syncthreads();
+    bar_lds();  // (LDS only: the next tile's two A requests keep flying under the epilogue)
     {
       const T* Cs = (const T*)smem;
 #pragma unroll
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS) void pig_kernel(const PigArgs g) {
     }
     if (!more) break;
     mtile = next;
-    __syncthreads();  // staging read: the next tile's weight DMA may overwrite it
+    bar_lds();  // staging read: the next tile's weight DMA may overwrite it
   }
   if (a.stat_sum != nullptr && tid < 2 * BN) {
     const int col = tid % BN, which = tid / BN;
@@ -234,6 +248,7 @@ hipError_t launch_pig(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (s.mode != G_PLAIN || s.istride != 1 || s.ntaps != 1 || s.taps[0] != 0 || s.Hs != a.Ho || s.Ws != a.Wo || s.scale == nullptr || s.q != nullptr)
     return hipErrorNotSupported;
   if (s.C % 8 || s.Cpad != s.C || a.Npad % PG_BN || a.out == nullptr) return hipErrorNotSupported;
+  if (2.0 * (double)a.M * s.ld >= 4294967296.0) return hipErrorNotSupported;  // 32-bit byte offsets into the operand
   if (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo || a.py != 0 || a.px != 0) return hipErrorNotSupported;
   const int lds = PG_MAIN + PG_EXTRA + 2 * s.C * 4 + 16;
   if (lds > 160 * 1024) return hipErrorNotSupported;
