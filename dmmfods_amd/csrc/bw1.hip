@@ -25,6 +25,12 @@ namespace dmm {
                   // GEMM, 4 no data-gradient GEMM, 8 no epilogue (staging, norm1 backward, store), 16 every load hits row 0,
                   // 32 the old gradient is not read (as if not accumulating), 64 the gradient is not stored
 #endif
+#ifndef B1_LATE_PREFETCH
+#define B1_LATE_PREFETCH 0  // experiment: the next tile's loads requested behind the GEMMs and the old gradient instead of in front of them
+#endif
+#ifndef B1_RAW_BAR
+#define B1_RAW_BAR 0        // experiment: raw s_barrier behind an LDS-only wait for the three barriers behind the prefetch
+#endif
 #ifndef B1_GOLD_EARLY
 #define B1_GOLD_EARLY 0  // 1: request the old gradient in front of the MFMAs (round 2; 16 more live registers across both GEMMs)
 #endif
@@ -203,7 +209,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
       }
     }
     __syncthreads();  // images (and, the first time, the weight slice) complete
+#if !B1_LATE_PREFETCH
     if (tile + 1 < t_end) issue(tile + 1);
+#endif
 #if B1_GOLD_EARLY
     if constexpr (ACC) {
 #pragma unroll
@@ -254,7 +262,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
       }
     }
 #endif
+#if B1_LATE_PREFETCH
+    if (tile + 1 < t_end) issue(tile + 1);
+#endif
+#if B1_RAW_BAR
+    // (experiment) The next tile's operands, requested BEHIND the old gradient: the epilogue's wait for the old gradient then leaves these twelve
+    // loads in flight, and the barriers from here to the end of the tile are raw s_barrier instructions behind an LDS-only wait -
+    // __syncthreads() is a fence (s_waitcnt vmcnt(0) on gfx9) and drained the prefetch at the first barrier behind it, half a
+    // microsecond after it had been issued.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all waves done with the images: stage the data-gradient tile over them
+#else
     __syncthreads();  // all waves done with the images: stage the data-gradient tile over them
+#endif
     if (B1_DBG & 8) {  // keep the data-gradient GEMM alive
       float sa = 0.f;
 #pragma unroll
@@ -271,7 +290,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
         const int row = 32 * (wave & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
         Cs[row * B1_CT + dcb + 32 * t + r] = accd[t][i];
       }
+#if B1_RAW_BAR
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     __syncthreads();
+#endif
     // ---- norm1 backward in the slot layout of the loads ----
     float s1[SLOT], s2[SLOT];
 #pragma unroll
@@ -307,7 +330,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     // up with 4 of the 16 finished wave totals), then fp64 in LDS - 4 LDS atomics per lane instead of 16 on a quarter of the lanes
     fold_to_lds<16, SLOT, B1_CT>(s1, s2, red, cs, cvalid, lane);
     }  // (epilogue)
+#if B1_RAW_BAR
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // staging read: the next tile's images may be written
+#else
     __syncthreads();  // staging read: the next tile's images may be written
+#endif
   }
 
   // ---- results of the walk: per-channel sums (one fp64 atomic per channel and workgroup), the weight-gradient slice ----
