@@ -57,6 +57,9 @@ constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
 #ifndef IGEMM_ASM_DMA
 #define IGEMM_ASM_DMA 0
 #endif
+#ifndef IGEMM_RAW_BAR
+#define IGEMM_RAW_BAR 0
+#endif
 #ifndef IGEMM_ADIST
 #define IGEMM_ADIST 1
 #endif
@@ -406,14 +409,24 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
   issue_b(0, 0);
   issue_a(RA, 0);
   if (ADIST == 2) issue_a(RB, 1);
+  // The barriers of the K loop.  __syncthreads() is a workgroup fence - on gfx9 an s_waitcnt vmcnt(0) - and drains the second register
+  // set's loads one stage after they were requested (round 3, pig.hip: that made ADIST = 2 worthless in round 2).  With two sets and a
+  // compile-time load count per issue_a the barrier is a raw s_barrier behind a COUNTED wait: everything but the newest request of
+  // the gathered operand - in particular the weight DMA of the stage, issued in front of it - has completed.
+  constexpr bool RAWBAR = IGEMM_RAW_BAR != 0 && ADIST == 2 && MFMA && PRO >= 0 && !(IGEMM_DBG & 1);
+  constexpr int NLOAD = NR * (PRO == 2 ? 2 : 1);
+  auto kbar = [&]() {
+    if constexpr (RAWBAR) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NLOAD) : "memory");
+    else __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+  };
   for (int it = 0; it < nstages; it += 2) {
     store_a(RA, 0);
-    __syncthreads();  // also retires this stage's weight LDS-DMA (vmcnt(0))
+    kbar();
     issue_b(1, it + 1);
     issue_a(RA, it + ADIST);  // past the end: dead stage (clamped loads, dropped)
     mma(0);
     store_a(RB, 1);
-    __syncthreads();
+    kbar();
     if (it + 2 < nstages) issue_b(0, it + 2);  // (the staging below reuses the image: no DMA may be left in flight)
     issue_a(RB, it + 1 + ADIST);
     mma(1);
@@ -675,6 +688,9 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
 // per CU) was +-1 %; every variant therefore takes 2 chunks per stage.
 // Measured on MI355X, C2 b4 (round 2), all kept as compile-time knobs and all OFF: (1) IGEMM_ASM_DMA + IGEMM_ADIST = 2 (counted
 // waits, two stages of the gathered operand in flight): store class -4 %, bnbwd class +3 % (264 VGPRs), step 33.8 vs 33.8 ms;
+// (1b, round 3) the same with raw counted barriers in the K loop (IGEMM_ADIST = 2 + IGEMM_RAW_BAR: __syncthreads drained the second set in
+// round 2's measurement): igemm.bnbwd 0.96 -> 0.93 ms, igemm.store +-0, step +-0 at C2; C1 (fp32) +-0 - its 60 us launches are 2048
+// v_mfma_f32_32x32x2_f32 per wave (64 cycles each) on 48 workgroups: bound by the fp32 matrix rate at 1/5 of the chip, not by loads;
 // (2) IGEMM_EPI_EARLY (epilogue operands of 1x1 data gradients requested before the K loop): +-0; (3) IGEMM_FAT (8-wave workgroups
 // that split K, for grids of <= DMM_FAT_WGS workgroups): 300-workgroup launches get SLOWER (block-3 1x1: 25 -> 38 us), step 34.1 ms.
 // Ablation builds (tools/conv_time.py with IGEMM_DBG) say why: with every load, the prologue math and the MFMAs removed a 1x1
