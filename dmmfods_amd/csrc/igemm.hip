@@ -718,7 +718,10 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
   // ones).  Narrower tiles for launches with few workgroups (DMM_MIN_WGS = n: halve the tile until the launch has n workgroups)
   // were measured on C2 b4 and do NOT help the small maps of blocks 3-4 / decoder stages 1-2 (33.57 ms/step at 0, 33.45 at 300,
   // 33.71 at 400, 34.13 at 1000): their cost is the length of each workgroup's chain of dependent stages, not idle CUs.
-  static const int min_wgs = getenv("DMM_MIN_WGS") ? atoi(getenv("DMM_MIN_WGS")) : 0;
+  // fp32 storage is the opposite case (round 3, C1 = 1x256x384): a 48-workgroup launch with K = 1024 is 2048 v_mfma_f32_32x32x2_f32 of 64
+  // cycles per wave - bound by the fp32 matrix rate of a fifth of the chip.  Narrower tiles spread the same MFMAs over more CUs:
+  // 16.7 -> 11.9 ms/step at 128 workgroups or more.  Default: 256 for fp32, 0 for the 16-bit types.
+  static const int min_wgs = getenv("DMM_MIN_WGS") ? atoi(getenv("DMM_MIN_WGS")) : (sizeof(T) == 4 ? 256 : 0);
   const int mtiles = (a.M + BM - 1) / BM;
   int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
   while (bn > 32 && mtiles * (a.Npad / bn) < min_wgs) bn >>= 1;

@@ -70,15 +70,17 @@ def test_baseline_architectures_against_reference_fixture(case, golden_dir):
     torch.testing.assert_close(met["acc_per_class"].cpu(), torch.from_numpy(g["acc"]).float(), rtol=1e-6, atol=px)
     # Gradients against the reference's own numbers.  Its fp32 CPU arithmetic is itself up to ~0.2 of a tensor's absmax away
     # from an fp64 run on the cancelling BatchNorm-parameter sums of a 121/201-layer net, so: convolution weights
-    # per tensor at 3e-2 of absmax, BatchNorm parameters with a loose per-tensor backstop, and a global relative L2 over all
-    # sampled elements.
+    # per tensor at 5e-2 of absmax (two fp32 summation orders against each other: 3.0e-2 was the worst tensor with 128-column
+    # tiles everywhere, 3.3e-2 with the narrower fp32 tiles of small launches - igemm.hip, DMM_MIN_WGS - while the global L2 and
+    # the noise-aware fp64 comparison below did not move), BatchNorm parameters with a loose per-tensor backstop, and a global
+    # relative L2 over all sampled elements.
     num = den = 0.0
     for k, p in model.named_parameters():
         mom, sample = g[f"grad/{k}/mom"], g[f"grad/{k}/sample"].astype(np.float64)
         assert p.numel() == int(mom[0]), k
         got = p.grad.detach().flatten()[:: int(mom[1])][: len(sample)].double().cpu().numpy()
         err = np.abs(got - sample).max() / max(mom[4], 1e-30)
-        assert err < (3e-2 if p.dim() == 4 else 0.5), (k, err)
+        assert err < (5e-2 if p.dim() == 4 else 0.5), (k, err)
         num += float(((got - sample) ** 2).sum())
         den += float((sample ** 2).sum())
     print(f"{case}: sampled-gradient rel L2 vs the reference fixture {(num / den) ** 0.5:.3e}")
