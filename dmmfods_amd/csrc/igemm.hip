@@ -45,6 +45,9 @@ template <> struct Mma<float> {
 #define IGEMM_KS128 2
 #endif
 constexpr int ks_for(int bn) { return bn == 128 ? IGEMM_KS128 : 2; }
+#ifndef IGEMM_FAT_F32
+#define IGEMM_FAT_F32 0  // experiment: 8-wave K-split variants for the 32-column fp32 tiles of launches with <= DMM_FAT_WGS workgroups
+#endif
 #ifndef IGEMM_FAT
 #define IGEMM_FAT 0  // instantiate the 8-wave variants (measured: no gain)
 #endif
@@ -698,8 +701,8 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
 // reductions and the stores of the epilogue), not latency that more bytes or waves in flight could hide.
 template <typename T, int BN, int EPI>
 static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
-  if constexpr (IGEMM_FAT && sizeof(T) == 2 && BN == 128 && EPI != EPI_LOGITS) {
-    static const int fat_wgs = getenv("DMM_FAT_WGS") ? atoi(getenv("DMM_FAT_WGS")) : 512;
+  if constexpr (((IGEMM_FAT && sizeof(T) == 2 && BN == 128) || (IGEMM_FAT_F32 && sizeof(T) == 4 && BN == 32)) && EPI != EPI_LOGITS) {
+    static const int fat_wgs = getenv("DMM_FAT_WGS") ? atoi(getenv("DMM_FAT_WGS")) : (sizeof(T) == 4 ? 128 : 512);
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += a.seg[s].nchunks;
     const int wgs = ((a.M + BM - 1) / BM) * (a.Npad / BN);
