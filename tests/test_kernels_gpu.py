@@ -64,3 +64,21 @@ def test_parity_phase_weight_gradients_on_lds_tiles(lab, dtype):
     finally:
         _lib.check(L.dmm_set_option(b"wgp", 1))
         _lib.check(L.dmm_set_option(b"cvp", 1))
+
+
+def test_lane_swap_fold_helper_alone(tmp_path):
+    """gather.h fold_to_lds (DPP row rotations + v_permlane32_swap / v_permlane16_swap) against a plain reduction for every
+    (slot columns, slot width) pair the kernels instantiate, full and partial column validity: tools/probes/fold_probe.hip, built here
+    with the toolchain of the box (the helper is header code; the probe instantiates combinations no shipped kernel uses any more)."""
+    import os, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fold_probe")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-Wno-unused-result",
+                    "-I", os.path.join(root, "dmmfods_amd", "csrc"), os.path.join(root, "tools", "probes", "fold_probe.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "FAIL" not in out.stdout, out.stdout + out.stderr
+    assert out.stdout.count(": ok") >= 11, out.stdout
