@@ -36,6 +36,9 @@ constexpr int C3_TH = 8, C3_TW = 16;
                   // loads hit one line, 2 no MFMA, 4 no weight DMA, 8 no epilogue, 16 no global statistics atomics, 32 no statistics
 #endif
 constexpr int C3_WRING = 3;  // weight ring slots
+#ifndef C3_RAW_EPI_BAR
+#define C3_RAW_EPI_BAR 0  // experiment (round 3): LDS-only raw barriers in the forward epilogue so that the next tile's halo loads are not drained: +-0
+#endif
 
 struct Conv3Args {
   ConvArgs c;
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       wpart[(wave * 2 + h) * BN + 32 * t + r] = fold_swap32(ps1[t], ps2[t]);  // lane half 0: the sum, half 1: the sum of squares
     }
   }
-  __syncthreads();
+  // (forward variants: a raw barrier behind an LDS-only wait - __syncthreads() is a fence, s_waitcnt vmcnt(0) on gfx9, and drained the
+  // next tile's halo loads here, a few hundred cycles after they had been requested)
+  if constexpr (PERSIST && C3_RAW_EPI_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
 
   if constexpr (EPI == EPI_STORE) {
     T* out = (T*)a.out;
@@ -413,7 +419,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   }  // (epilogue)
   if (!more) break;
   lt = lnext;
-  __syncthreads();  // staging / reduction scratch read: the next tile may overwrite the images, the ring, rowpix and red
+  // staging / reduction scratch read: the next tile may overwrite the images, the ring, rowpix and red
+  if constexpr (PERSIST && C3_RAW_EPI_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
   }  // (tile loop)
 }
 
