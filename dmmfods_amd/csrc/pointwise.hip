@@ -408,34 +408,61 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 // Materialise the deferred BatchNorm-backward correction of a gradient tensor that will be gathered many times
 // (several taps / output tiles / K groups): afterwards its consumers read a plain tensor.
+// A thread owns ONE channel slot (its eight q / r / ql / rl constants stay in registers for the whole launch: fetched per element they were
+// eight times the bytes of the tensors themselves, from cache) and walks pixels four at a time (eight 16-byte loads in flight).
 template <typename T>
-__global__ __launch_bounds__(256) void apply_corr_kernel(ApplyCorrArgs a) {
+__global__ __launch_bounds__(256) void apply_corr_kernel(ApplyCorrArgs a, unsigned rows_per_step) {
   constexpr int SLOT = TT<T>::SLOT;
   typedef typename TT<T>::vec V;
-  const int ncs = a.C / SLOT;
-  const size_t total = a.npix * ncs;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t p = i / ncs;
-    const int c = (int)(i - p * ncs) * SLOT;
-    T* gp = (T*)a.g + p * a.ldg + c;
-    float f[SLOT], y[SLOT], q[SLOT], r[SLOT], ql[SLOT], rl[SLOT];
-    vec_to_f32<T>(*(const V*)gp, f);
-    vec_to_f32<T>(*(const V*)((const T*)a.y + p * a.ldy + c), y);
-    load_f32s<SLOT>(a.q + c, q); load_f32s<SLOT>(a.r + c, r); load_f32s<SLOT>(a.ql + c, ql); load_f32s<SLOT>(a.rl + c, rl);
+  const unsigned ncs = (unsigned)(a.C / SLOT);
+  const unsigned gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned cs = gtid % ncs, prow = gtid / ncs;
+  if (prow >= rows_per_step) return;  // (the grid is rounded up to whole blocks)
+  const int c = (int)cs * SLOT;
+  float q[SLOT], r[SLOT], ql[SLOT], rl[SLOT];
+  load_f32s<SLOT>(a.q + c, q); load_f32s<SLOT>(a.r + c, r); load_f32s<SLOT>(a.ql + c, ql); load_f32s<SLOT>(a.rl + c, rl);
+  T* gbase = (T*)a.g + c;
+  const T* ybase = (const T*)a.y + c;
+  constexpr int U = 4;
+  size_t p = prow;
+  for (; p + (size_t)(U - 1) * rows_per_step < a.npix; p += (size_t)U * rows_per_step) {
+    V gv[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t pp = p + (size_t)u * rows_per_step;
+      gv[u] = *(const V*)(gbase + pp * a.ldg);
+      yv[u] = *(const V*)(ybase + pp * a.ldy);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float f[SLOT], y[SLOT];
+      vec_to_f32<T>(gv[u], f);
+      vec_to_f32<T>(yv[u], y);
+#pragma unroll
+      for (int k = 0; k < SLOT; ++k) f[k] = (f[k] + fmaf(r[k], y[k], q[k])) + fmaf(rl[k], y[k], ql[k]);
+      *(V*)(gbase + (p + (size_t)u * rows_per_step) * a.ldg) = f32_to_vec<T>(f);
+    }
+  }
+  for (; p < a.npix; p += rows_per_step) {
+    float f[SLOT], y[SLOT];
+    vec_to_f32<T>(*(const V*)(gbase + p * a.ldg), f);
+    vec_to_f32<T>(*(const V*)(ybase + p * a.ldy), y);
 #pragma unroll
     for (int k = 0; k < SLOT; ++k) f[k] = (f[k] + fmaf(r[k], y[k], q[k])) + fmaf(rl[k], y[k], ql[k]);
-    *(V*)gp = f32_to_vec<T>(f);
+    *(V*)(gbase + p * a.ldg) = f32_to_vec<T>(f);
   }
 }
 
 hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st) {
-  const size_t total = a.npix * (a.C / (dtype == DT_F32 ? 4 : 8));
-  int grid = (int)((total + 255) / 256);
-  if (grid > 16384) grid = 16384;
-  if (grid < 1) return hipSuccess;
-  if (dtype == DT_F16) hipLaunchKernelGGL(apply_corr_kernel<f16>, dim3(grid), dim3(256), 0, st, a);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(apply_corr_kernel<bf16>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(apply_corr_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+  const unsigned ncs = (unsigned)(a.C / (dtype == DT_F32 ? 4 : 8));
+  if (ncs == 0 || a.npix == 0) return hipSuccess;
+  // pixel rows walked side by side: up to ~4 M threads, a whole number of channel-slot groups
+  size_t rows = std::min<size_t>(a.npix, std::max<size_t>(1, (size_t)(16384 * 256) / ncs));
+  const size_t threads = rows * ncs;
+  const int grid = (int)((threads + 255) / 256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(apply_corr_kernel<f16>, dim3(grid), dim3(256), 0, st, a, (unsigned)rows);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(apply_corr_kernel<bf16>, dim3(grid), dim3(256), 0, st, a, (unsigned)rows);
+  else hipLaunchKernelGGL(apply_corr_kernel<float>, dim3(grid), dim3(256), 0, st, a, (unsigned)rows);
   return hipGetLastError();
 }
 
