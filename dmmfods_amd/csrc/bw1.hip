@@ -340,8 +340,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   // ---- results of the walk: per-channel sums (one fp64 atomic per channel and workgroup), the weight-gradient slice ----
   if (tid < B1_CT && c0 + tid < a.N) {
     const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-    atomic_add_f64(a.red1 + rep + c0 + tid, red[tid]);
-    atomic_add_f64(a.red2 + rep + c0 + tid, red[B1_CT + tid]);
+    atomic_add_f64(a.red1 + rep + c0 + tid, red[fold_slot<16, SLOT>(0, tid)]);
+    atomic_add_f64(a.red2 + rep + c0 + tid, red[fold_slot<16, SLOT>(1, tid)]);
   }
   const int c = c0 + 32 * wave + r;
   if constexpr (PART) {  // this workgroup's slot, in the layout of the dpack slice (whole slot: the reduction reads all of it)

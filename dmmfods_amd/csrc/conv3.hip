@@ -412,8 +412,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     __syncthreads();
     if (!(C3_DBG & (16 | 32)) && tid < BN && tid < a.N) {
       const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-      atomic_add_f64(a.red1 + rep + tid, red[tid]);
-      atomic_add_f64(a.red2 + rep + tid, red[BN + tid]);
+      atomic_add_f64(a.red1 + rep + tid, red[fold_slot<NCV, SLOT>(0, tid)]);
+      atomic_add_f64(a.red2 + rep + tid, red[fold_slot<NCV, SLOT>(1, tid)]);
     }
   }
   }  // (epilogue)

@@ -474,8 +474,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   __syncthreads();
   if (tid < BN && n0 + tid < a.N) {
     const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-    atomic_add_f64(a.red1 + rep + n0 + tid, red[tid]);
-    atomic_add_f64(a.red2 + rep + n0 + tid, red[BN + tid]);
+    atomic_add_f64(a.red1 + rep + n0 + tid, red[fold_slot<NCV, SLOT>(0, tid)]);
+    atomic_add_f64(a.red2 + rep + n0 + tid, red[fold_slot<NCV, SLOT>(1, tid)]);
   }
 }
 

@@ -423,9 +423,16 @@ __device__ __forceinline__ void fold_rows(const float (&v)[4 * NQ], float (&w)[N
 
 // Epilogue reductions of the convolution kernels: every lane holds partials s1[SLOT] | s2[SLOT] of its slot column cv = lane % NCV
 // (NCV = 4, 8, 16 or 32 columns; the lanes l, l + NCV, ... of a wave share a column).  Adds the wave totals to the workgroup's fp64
-// accumulators red[0 .. BN) (s1) and red[BN .. 2 BN) (s2) in LDS.  Lanes inside a 16-lane row are folded by DPP row rotations
+// accumulators red[fold_slot(0, ch)] (s1) and red[fold_slot(1, ch)] (s2) in LDS.  Lanes inside a 16-lane row are folded by DPP row rotations
 // (one v_add_f32 each), the rows by fold_rows: every lane is left with a quarter of the column's totals and issues SLOT/2 LDS atomics
 // (a __shfl_xor per step and value, then 2 SLOT atomics on 1/4 .. 1/16 of the lanes before round 3).
+// Layout of the accumulators: VALUE-major - red[v * NCV + cv], v = which * SLOT + e - so that the lanes of one LDS atomic (16 / 8 / 4
+// columns x the four values the rows hold) touch 64 / 32 / 16 CONSECUTIVE doubles: every bank the minimum number of times.  (Channel-major,
+// as in round 2, the 64 lanes met 4-deep on a quarter of the banks: SQ_LDS_BANK_CONFLICT per LDS-active cycle 0.49 -> 0.76 on bw1 when all
+// lanes started to issue these atomics.)  fold_slot: where channel ch of the tile (ch = cv * SLOT + e) keeps sum `which`.
+template <int NCV, int SLOT>
+__device__ __forceinline__ int fold_slot(int which, int ch) { return (which * SLOT + (ch % SLOT)) * NCV + ch / SLOT; }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
@@ -441,7 +448,7 @@ __device__ __forceinline__ void fold_to_lds(const float (&s1)[SLOT], const float
     for (int k = 0; k < SLOT; ++k) {
       const float t = fold_swap32(v[2 * k], v[2 * k + 1]);  // lanes 0-31: value 2k, lanes 32-63: value 2k+1
       const int vi = 2 * k + (lane >> 5);
-      if (colvalid) atomicAdd(&red[(vi >= SLOT ? BN : 0) + cv * SLOT + (vi & (SLOT - 1))], (double)t);
+      if (colvalid) atomicAdd(&red[vi * NCV + cv], (double)t);
     }
   } else {
     if constexpr (NCV <= 8) {
@@ -459,7 +466,7 @@ __device__ __forceinline__ void fold_to_lds(const float (&s1)[SLOT], const float
 #pragma unroll
       for (int m = 0; m < SLOT / 2; ++m) {
         const int vi = 4 * m + pick;
-        atomicAdd(&red[(vi >= SLOT ? BN : 0) + cv * SLOT + (vi & (SLOT - 1))], (double)w[m]);
+        atomicAdd(&red[vi * NCV + cv], (double)w[m]);
       }
     }
   }

@@ -625,8 +625,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
     if (colvalid && lane < NCV) {
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
-        atomicAdd(&red[cv * SLOT + i], (double)s1[i]);
-        atomicAdd(&red[BN + cv * SLOT + i], (double)s2[i]);
+        atomicAdd(&red[fold_slot<NCV, SLOT>(0, cv * SLOT + i)], (double)s1[i]);
+        atomicAdd(&red[fold_slot<NCV, SLOT>(1, cv * SLOT + i)], (double)s2[i]);
       }
     }
   } else {
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
     double* d1 = (EPI == EPI_STORE) ? a.stat_sum : a.red1;
     double* d2 = (EPI == EPI_STORE) ? a.stat_sq : a.red2;
     const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-    atomic_add_f64(d1 + rep + n0 + tid, red[tid]);
-    atomic_add_f64(d2 + rep + n0 + tid, red[BN + tid]);
+    atomic_add_f64(d1 + rep + n0 + tid, red[fold_slot<NCV, SLOT>(0, tid)]);
+    atomic_add_f64(d2 + rep + n0 + tid, red[fold_slot<NCV, SLOT>(1, tid)]);
   }
 }
 

@@ -20,7 +20,7 @@ __global__ void k(const float* in, double* out, int ncolvalid) {
   const int cv = tid % NCV;
   fold_to_lds<NCV, SLOT, BN>(s1, s2, red, cv, cv < ncolvalid, lane);
   __syncthreads();
-  for (int i = tid; i < 2 * BN; i += blockDim.x) out[i] = red[i];
+  for (int i = tid; i < BN; i += blockDim.x) { out[i] = red[fold_slot<NCV, SLOT>(0, i)]; out[BN + i] = red[fold_slot<NCV, SLOT>(1, i)]; }
 }
 
 template <int NCV, int SLOT>
