@@ -288,7 +288,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = 32 * (wave & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
-        Cs[row * B1_CT + dcb + 32 * t + r] = accd[t][i];
+        // (row bit 2 = the lane half h: rows of the upper half go to the OTHER 32 banks - columns ^ 32 - instead of on top of the lower
+        // half's; the readers apply the same XOR, which keeps their 16-byte groups intact)
+        Cs[row * B1_CT + ((dcb + 32 * t + r) ^ (h << 5))] = accd[t][i];
       }
 #if B1_RAW_BAR
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
         float av[SLOT], xf[SLOT], gf[SLOT];
 #pragma unroll
         for (int e = 0; e < SLOT; e += 4) {
-          const f32x4 t4 = *(const f32x4*)(Cs + p * B1_CT + cs * SLOT + e);
+          const f32x4 t4 = *(const f32x4*)(Cs + p * B1_CT + ((cs * SLOT + e) ^ (((p >> 2) & 1) << 5)));
           av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
         }
         vec_to_f32<T>(xraw[i], xf);
