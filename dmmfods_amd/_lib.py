@@ -54,6 +54,9 @@ def lib():
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     L.dmm_last_error.restype = C.c_char_p
     L.dmm_version.restype = C.c_int
+    L.dmm_last_impl.restype = C.c_int
+    L.dmm_impl_name.restype = C.c_char_p
+    L.dmm_impl_name.argtypes = [C.c_int]
     L.dmm_set_option.restype = C.c_int
     L.dmm_set_option.argtypes = [C.c_char_p, C.c_int]
     L.dmm_plan_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
@@ -108,7 +111,7 @@ EXPORTS = [
     "dmm_plan_loss_metrics", "dmm_plan_num_graph_replays", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
     "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
-    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused",
+    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused", "dmm_last_impl", "dmm_impl_name",
 ]
 
 
@@ -124,6 +127,12 @@ def check(rc):
     if rc == ERR_INVALID:
         raise ValueError(msg)
     raise DmmError(f"dmm status {rc}: {msg}")
+
+
+def last_impl():
+    """Name of the kernel family that ran this thread's most recent single-kernel launch ("wg3", "conv3", "generic", ...)."""
+    L = lib()
+    return L.dmm_impl_name(L.dmm_last_impl()).decode()
 
 
 def stream_ptr():

@@ -415,9 +415,10 @@ Bw1Geom bw1_geometry(const ConvArgs& a) {
   Bw1Geom q;
   q.nct = (a.N + B1_CT - 1) / B1_CT;
   q.ntiles = (a.M + B1_TM - 1) / B1_TM;
-  static const int cus = [] { hipDeviceProp_t pr; int dev = 0;
-                              return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-                                         ? pr.multiProcessorCount : 256; }();
+  // A pure function of the shape: the plan's sizing pass reserves the slots from it WITHOUT a GPU (dmm_plan_create /
+  // dmm_plan_workspace_bytes never touch the HIP runtime), and a launch must split exactly as the plan reserved.  The split is laid
+  // out for the 256 compute units of the MI355X this library is written for.
+  constexpr int cus = DESIGN_CUS;
   static const int per_cu = getenv("DMM_BW1_PER_CU") ? atoi(getenv("DMM_BW1_PER_CU")) : 2;
   // every workgroup ends with 64 KB of weight gradient to hand over and a tile is ~2 us of work: at least 4 tiles per workgroup
   int nsplit = std::max(1, (per_cu * cus + q.nct - 1) / q.nct);
@@ -441,6 +442,7 @@ hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
   const ConvArgs& a = g.c;
   if (a.M <= 0) return hipSuccess;
   const Bw1Geom q = bw1_geometry(a);
+  g_last_impl = IMPL_BW1;
   g.nct = q.nct; g.ntiles = q.ntiles; g.tiles_per_wg = q.tiles_per_wg; g.xcd_group = q.xcd_group; g.nsplit = q.nsplit;
   const int nwg = q.nwg;
   const int pq = a.seg[0].q ? 2 : 0;

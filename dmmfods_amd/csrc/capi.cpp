@@ -604,6 +604,12 @@ static void fill_one_seg(Seg& s, const dmm_conv_desc* d, const OneConv& g, const
   fill_seg_taps(s, taps, g.BK);
 }
 
+int dmm_last_impl(void) { return g_last_impl; }
+const char* dmm_impl_name(int impl) {
+  static const char* const names[IMPL_COUNT] = {"auto", "generic", "thin", "conv3", "cvp", "halo", "wg3", "wg5", "wgp", "pig", "bw1"};
+  return impl >= 0 && impl < IMPL_COUNT ? names[impl] : "?";
+}
+
 int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, const float* scale, const float* shift, void* y,
                      double* stats, void* scratch, void* stream) {
   OneConv g;
@@ -693,7 +699,15 @@ int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, con
     a.dy.istride = 1;
     a.N = g.Cst; a.Npad = pd.Npad;
     a.dpack = (float*)pd.dpack;
-    HIPCHK(launch_wgrad(a, d->dtype, d->use_mfma != 0, st));
+    void* part = nullptr;
+    if (d->use_mfma && wg3_handles(a, d->dtype)) {  // the plan gives the family its slots; so does this entry point
+      HIPCHK(hipMallocAsync(&part, (size_t)W3_MAX_SLOTS * W3_SLOT_FLOATS * sizeof(float), st));
+      a.part = (float*)part;
+      a.part_slots = W3_MAX_SLOTS;
+    }
+    const hipError_t e1 = launch_wgrad(a, d->dtype, d->use_mfma != 0, st);
+    if (part != nullptr) hipFreeAsync(part, st);
+    HIPCHK(e1);
     HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
     HIPCHK(launch_unpack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, 1.0f, st));
     return DMM_OK;

@@ -40,6 +40,7 @@ constexpr int MAX_TAPS = 52;
 #define DMM_STAT_REPS 8
 #endif
 constexpr int STAT_REPS = DMM_STAT_REPS;  // replicas of the BatchNorm reduction accumulators (low 3 bits of the workgroup id = XCD)
+constexpr int DESIGN_CUS = 256; // compute units of the MI355X: launch geometries that size plan workspace are computed for it, not queried
 constexpr int BM = 128;        // rows (pixels) per workgroup tile
 constexpr int NTHREADS = 256;  // 4 waves of 64
 constexpr int ROWB = 64;       // LDS bytes per tile row = one K-chunk; the four 16-byte slots of a row are XOR-swizzled
@@ -111,18 +112,27 @@ struct WgradArgs {
   float* dpack;  // fp32 packed gradient [chunk][Npad][BK]
   int rows_per_split;  // multiple of BM
   int kgroups;         // number of K groups (each WG_CHUNKS chunks)
+  // wg3.hip: per-workgroup slots for the partial results (nullable: fp32 atomics into dpack).  One buffer serves every launch of
+  // the family - they run in order on one stream and each is followed by its reduction.
+  float* part;
+  int part_slots;      // capacity of `part` in slots of W3_SLOT_FLOATS
 };
+constexpr int W3_SLOT_FLOATS = 9 * 128 * 32;  // one workgroup's partial result of the dense 3x3 weight gradient (147 KB)
+constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at most (device-independent: plans are sized without a GPU)
 
 // Kernel family of a convolution / weight-gradient launch.  A plan decides it ONCE per launch when it is built (igemm_pick /
 // wgrad_pick walk the dispatch without launching and honour the dmm_set_option switches of that moment) and the executor
 // dispatches from the recorded value, so a plan's labels, its profile classes and the kernels it runs cannot drift apart when an
 // option is toggled afterwards.  IMPL_AUTO (the single-kernel test entry points): decide at the call.
-enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG };
+enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG, IMPL_BW1, IMPL_COUNT };
 struct LaunchCtl {
   bool dry = false;      // walk the eligibility tests, launch nothing
   int impl = IMPL_AUTO;  // the one family allowed to take the launch (IMPL_AUTO: every enabled family, in dispatch order)
 };
 extern thread_local LaunchCtl g_ctl;  // (defined in pointwise.hip)
+// The family that took the calling thread's most recent convolution / weight-gradient / fused-backward launch (dmm_last_impl):
+// a per-kernel test asserts the family it names really ran - IMPL_AUTO falls back to the generic kernels silently.
+extern thread_local int g_last_impl;
 inline bool family_on(bool enabled, int family) { return g_ctl.impl == IMPL_AUTO ? enabled : g_ctl.impl == family; }
 
 #if defined(__HIPCC__)

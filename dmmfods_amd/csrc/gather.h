@@ -397,12 +397,23 @@ __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSl
 //   in:  v[0 .. 4 NQ)   this lane's partials
 //   out: w[m], m < NQ = the wave total (over lanes l, l^16, l^32, l^48) of value 4 m + fold_pick(lane)
 // (The builtins: hipcc pads the 2 wait states the swaps need behind a VALU write of either operand itself - cdna_hip_programming.md T21.)
+#ifndef FOLD_VARIANT
+#define FOLD_VARIANT 0  // experiment builds: bit 0 the lane swaps as ds_bpermute shuffles (same sums, same order), bit 1 the DPP row rotations as shuffles
+#endif
 __device__ __forceinline__ float fold_swap32(float a, float b) {  // lanes 0-31: a(l) + a(l+32); lanes 32-63: b(l-32) + b(l)
+  if constexpr (FOLD_VARIANT & 1) {
+    const float ax = __shfl_xor(a, 32, 64), bx = __shfl_xor(b, 32, 64);
+    return (__lane_id() & 32) ? bx + b : a + ax;
+  }
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float fold_swap16(float a, float b) {  // rows 0,2: a(row) + a(row+1); rows 1,3: b(row-1) + b(row)
+  if constexpr (FOLD_VARIANT & 1) {
+    const float ax = __shfl_xor(a, 16, 64), bx = __shfl_xor(b, 16, 64);
+    return (__lane_id() & 16) ? bx + b : a + ax;
+  }
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -435,6 +446,7 @@ __device__ __forceinline__ int fold_slot(int which, int ch) { return (which * SL
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
+  if constexpr (FOLD_VARIANT & 2) return v + __shfl_xor(v, CTRL == 0x128 ? 8 : 4, 64);  // (row_ror:8 / :4 on values already equal across the rotated halves)
   return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
 template <int NCV, int SLOT, int BN>

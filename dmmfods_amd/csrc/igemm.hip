@@ -426,11 +426,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
     store_a(RA, 0);
     kbar();
     issue_b(1, it + 1);
+    if constexpr (RAWBAR) __builtin_amdgcn_sched_barrier(0);  // the counted wait assumes DMA-before-loads in issue order (pig.hip)
     issue_a(RA, it + ADIST);  // past the end: dead stage (clamped loads, dropped)
     mma(0);
     store_a(RB, 1);
     kbar();
     if (it + 2 < nstages) issue_b(0, it + 2);  // (the staging below reuses the image: no DMA may be left in flight)
+    if constexpr (RAWBAR) __builtin_amdgcn_sched_barrier(0);
     issue_a(RB, it + 1 + ADIST);
     mma(1);
   }
@@ -789,8 +791,9 @@ hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStr
     int took;
     const hipError_t e = dispatch_special(a, dtype, epi, st, took);
     g_ctl = keep;
-    if (e != hipErrorNotSupported) return e;
+    if (e != hipErrorNotSupported) { g_last_impl = took; return e; }
   }
+  g_last_impl = IMPL_GENERIC;
   if (dtype == DT_F16) return launch_igemm_type<f16>(a, epi, mfma, st);
   if (dtype == DT_BF16) return launch_igemm_type<bf16>(a, epi, mfma, st);
   return launch_igemm_type<float>(a, epi, mfma, st);

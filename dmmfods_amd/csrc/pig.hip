@@ -181,11 +181,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void pig_kernel(const PigArgs g) {
       store_a(RA, 0);
       if (it == 0) bar_all(); else bar_keep();  // the weight DMA of this stage has landed (it == 0: it was the newest request)
       issue_b(1, it + 1);
+      // bar_keep's vmcnt(NR) assumes the weight DMA is OLDER in issue order than the NR loads of issue_a: nothing else orders an
+      // LDS-DMA builtin against plain loads it does not alias, so pin the order (no instruction crosses a sched_barrier(0))
+      __builtin_amdgcn_sched_barrier(0);
       issue_a(RA);                              // stage it + 2 (or the next tile's: the cursor runs on)
       mma(0);
       store_a(RB, 1);
       bar_keep();
       if (it + 2 < nstages) issue_b(0, it + 2);  // (the staging below reuses the image: no DMA may be left in flight)
+      __builtin_amdgcn_sched_barrier(0);
       issue_a(RB);
       mma(1);
     }

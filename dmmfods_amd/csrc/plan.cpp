@@ -426,6 +426,8 @@ struct Builder {
 
   // -------------------------------------------------------------------------------- op emission
   bool leaf_scope = false;  // ops emitted now feed only parameter gradients (stem / raw-input branches)
+  float* wg3_part = nullptr;  // wg3.hip's slots, shared by every launch of the family
+  bool wg3_part_taken = false;
   const bool front_matz = getenv("DMM_NO_FRONT_MATZ") == nullptr;  // A/B knob
   // which multi-consumer gradients are materialised (q + r*y applied once by applycorr) instead of corrected by every consumer's
   // prologue: 1 the decoder's conv_reduce outputs, 2 the last ConvTranspose's output, 4 refine0's output (A/B knob)
@@ -632,6 +634,13 @@ struct Builder {
       const PackDesc& pd = P.packs[c.dpack[0]];
       a.N = c.seg[0].C; a.Npad = pd.Npad;
       a.dpack = (float*)pd.dpack;
+      // wg3.hip's per-workgroup slots: ONE buffer for all launches of the family (they run in order on one stream, each followed
+      // by its reduction).  Reserved by the shape alone: the sizing pass and the bound pass must take the same bytes.
+      if (dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.seg[0].C == 128 && getenv("DMM_WG3_SLOTS_OFF") == nullptr) {
+        if (!wg3_part_taken) { wg3_part = wptr<float>((size_t)W3_MAX_SLOTS * W3_SLOT_FLOATS); wg3_part_taken = true; }
+        a.part = wg3_part;
+        a.part_slots = W3_MAX_SLOTS;
+      }
       char cb[32];
       o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
       tag(o, ncls(o.impl == IMPL_WG3 ? "wg3" : (o.impl == IMPL_WG5 ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
@@ -1121,7 +1130,10 @@ struct Builder {
       const Rec& r = recs[ri];
       const bool beside = g.fusion == 2 && s2_overlap && s2_recs > 0;
       if (beside && ri == concat_rec) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
-      leaf_scope = beside && ri < s2_recs;
+      // (record 0 - the second stream's stem, whose weights are the "stem" pack - stays on the launch stream: as a leaf it queued
+      // on the side stream BEHIND the pack of all other weights, and the join behind it then made the first stream's stem wait for
+      // both; now it runs beside that pack, which is what the pack split is for)
+      leaf_scope = beside && ri < s2_recs && (ri > 0 || pack_split == 0);
       if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
       leaf_scope = false;
       if (ri == 0) emit_pack_join();
@@ -1147,23 +1159,36 @@ struct Builder {
     throw std::runtime_error("gradient offset outside every bucket");
   }
   void make_buckets() {
-    // whole tensors in .parameters() order, closed once they reach the target size
+    // Whole tensors in .parameters() order (a bucket is one contiguous slice of the arena), closed
+    //   * once they reach the target size;
+    //   * where backward finishes a part of the network long before the next one: at the boundaries of the top-level modules
+    //     (features, stream_2_features, concat_module, decoder, head) and, INSIDE an encoder, of its dense blocks / transitions, as
+    //     soon as >= 4 MB (1 MB at a top-level boundary) have gathered.  Backward walks an encoder from block 4 down to conv0, i.e. from the END of its slice to the
+    //     front: without these cuts conv0 ... most of block 4 of DenseNet-121 were ONE bucket that became ready with conv0's weight
+    //     gradient, the very last launch (round 3: bucket_mb [0.3, 17.1, 41.4, 25.2], 25 MB behind the end of backward); with them
+    //     the last bucket is stem + blocks 1-2 (5 MB);
+    //   * in front of and behind a single tensor of at least the target size (the first ConvTranspose of the decoder is 38 MB).
     brecs.clear();
     const int64_t target = (int64_t)(P.bucket_bytes / 4);
+    const int64_t cut_min = (4 << 20) / 4;
     BucketRec cur;
     std::string group;
+    auto close = [&]() { if (cur.n > 0) { brecs.push_back(cur); cur = BucketRec(); } };
     for (auto& t : P.tensors) {
       if (t.kind > DMM_T_BN_BIAS) continue;
       int64_t n = 1;
       for (int k = 0; k < t.ndim; ++k) n *= t.shape[k];
-      // the top-level modules (features, decoder, head, stream_2_features, concat_module) finish at very different times:
-      // do not let a sizeable bucket run across such a boundary
-      const std::string grp = t.name.substr(0, t.name.find('.'));
-      if (target > 0 && grp != group && cur.n * 4 >= (4 << 20)) { brecs.push_back(cur); cur = BucketRec(); }
+      const size_t d1 = t.name.find('.');
+      std::string grp = t.name.substr(0, d1);
+      if ((grp == "features" || grp == "stream_2_features") && d1 != std::string::npos)
+        grp = t.name.substr(0, t.name.find('.', d1 + 1));  // features.denseblock3, features.transition2, features.conv0 ...
+      const bool top_change = grp.substr(0, grp.find('.')) != group.substr(0, group.find('.'));
+      if (target > 0 && grp != group && cur.n >= (top_change ? cut_min / 4 : cut_min)) close();
+      if (target > 0 && n >= target) close();
       group = grp;
       if (cur.n == 0) cur.off = t.off;
       cur.n += n;
-      if (target > 0 && cur.n >= target) { brecs.push_back(cur); cur = BucketRec(); }
+      if (target > 0 && cur.n >= target) close();
     }
     if (cur.n > 0) brecs.push_back(cur);
     for (auto& c : convs) brecs[bucket_of(T(c.wname).off)].convs_left++;

@@ -13,6 +13,7 @@
 namespace dmm {
 
 thread_local LaunchCtl g_ctl;  // see common.h
+thread_local int g_last_impl = IMPL_AUTO;
 
 // ---------------------------------------------------------------------------------------------------
 template <typename T>

@@ -5,7 +5,8 @@ H:125-133, but never instantiated by an agent).  The arithmetic is the loss epil
   * ``model.set_loss("focal", alpha, gamma)`` (or ``loss.attach(model)``) makes the fused training tail
     ``model.loss_backward`` / ``model.loss_metrics`` compute the focal loss sums and backpropagate d(sum F)/d(logit);
   * calling the module on device tensors runs the same kernel stand-alone (``dmm_loss_forward``): unreduced loss forward,
-    the analytic derivative the kernel produced in backward.  There is no CPU path.
+    the analytic derivative the kernel produced in backward.  There is no CPU path.  The kernel computes in fp32 whatever the
+    input dtype (fp64 inputs are rounded to fp32 first and the result is cast back: the reference's fp64 precision is NOT kept).
 """
 import ctypes as C
 
@@ -64,52 +65,69 @@ class FocalLoss(nn.Module):
         super().__init__()
         self.alpha, self.gamma, self.logits, self.reduce = alpha, gamma, logits, reduce
 
-    def _per_class(self, nclass, exact=True):
+    @staticmethod
+    def _per_class(nclass, alpha, gamma, exact=True):
+        """alpha / gamma as lists of `nclass` floats (a scalar is repeated; a shorter list is padded with the values that give zero
+        loss when ``exact`` is False).  Pure function of its arguments: forward() never rebinds the module's attributes, so concurrent
+        calls on one module cannot see each other's values."""
         def expand(v, pad):
             v = [float(v)] * nclass if not hasattr(v, "__len__") else [float(e) for e in v]
             if len(v) > nclass or (exact and len(v) != nclass):
                 raise ValueError(f"expected {nclass} per-class values, got {len(v)}")
             return v + [pad] * (nclass - len(v))
-        return expand(self.alpha, 0.0), expand(self.gamma, 1.0)
+        return expand(alpha, 0.0), expand(gamma, 1.0)
 
     def attach(self, model):
         """Select this loss as the epilogue of the model's fused training tail (logits only, as the tail sees logits)."""
         if not self.logits:
             raise ValueError("the fused training tail works on logits: construct the loss with logits=True")
-        alpha, gamma = self._per_class(int(model.num_classes))
+        alpha, gamma = self._per_class(int(model.num_classes), self.alpha, self.gamma)
         model.set_loss("focal", alpha, gamma)
         return model
 
+    @staticmethod
+    def _is_scalar(v):
+        return isinstance(v, (int, float)) or (torch.is_tensor(v) and v.dim() == 0)
+
     def forward(self, inputs, targets):
-        # scalar alpha / gamma act element-wise: any shape is one "class" of numel elements
         shape = inputs.shape
         x = inputs.reshape(1, 1, 1, -1)
         t = targets.reshape(1, 1, 1, -1)
-        alpha, gamma = [float(self.alpha)], [float(self.gamma)]
-        loss = _HipLoss.apply(x, t, _lib.LOSS_FOCAL, not self.logits, alpha, gamma).reshape(shape)
+        if self._is_scalar(self.alpha) and self._is_scalar(self.gamma):
+            # scalar alpha / gamma act element-wise: any shape is one "class" of numel elements, all of it in the HIP epilogue
+            loss = _HipLoss.apply(x, t, _lib.LOSS_FOCAL, not self.logits, [float(self.alpha)], [float(self.gamma)]).reshape(shape)
+        else:
+            # tensor / sequence alpha or gamma: the reference's expression (L:44-45) broadcasts them against the loss tensor.  The
+            # unreduced BCE (and its derivative) come from the HIP kernel; the broadcast itself is torch glue on the device.
+            bce = _HipLoss.apply(x, t, _lib.LOSS_BCE, not self.logits, [1.0], [0.0]).reshape(shape)
+            alpha = torch.as_tensor(self.alpha, dtype=bce.dtype, device=bce.device)
+            gamma = torch.as_tensor(self.gamma, dtype=bce.dtype, device=bce.device)
+            loss = alpha * (1 - torch.exp(-bce)) ** gamma * bce
         return loss.mean() if self.reduce else loss
 
 
 class ClassWiseFocalLoss(FocalLoss):
     """Per-class alpha (class-class imbalance) and gamma (class-background imbalance); inputs are (B, C, H, W).  As in the reference
-    (L:78-91, a loop over zip(alpha, gamma)) classes beyond the listed values get zero loss."""
+    (L:78-91, a loop over zip(alpha, gamma)): lists of different lengths are cut to the shorter one, classes beyond the listed
+    values get zero loss, more listed values than channels raise IndexError."""
 
     def __init__(self, alpha=(1, 1, 1), gamma=(2, 2, 2), logits=True, reduce=False):
         super().__init__(list(alpha), list(gamma), logits, reduce)
-        if len(self.alpha) != len(self.gamma):
-            raise ValueError("alpha and gamma must have the same length")
 
     def forward(self, inputs, targets):
         if inputs.dim() != 4:
             raise ValueError("expected inputs and targets structured like batches x classes x X x Y")
-        n = min(len(self.alpha), len(self.gamma))
+        n = min(len(self.alpha), len(self.gamma))   # zip() stops at the shorter list
         if n > inputs.shape[1]:
             raise IndexError(f"{n} per-class values for {inputs.shape[1]} classes")   # the reference's F_loss[:, i] raises the same
-        self_alpha, self_gamma = self.alpha, self.gamma
-        self.alpha, self.gamma = self_alpha[:n], self_gamma[:n]
-        try:
-            alpha, gamma = self._per_class(inputs.shape[1], exact=False)
-        finally:
-            self.alpha, self.gamma = self_alpha, self_gamma
+        alpha, gamma = self._per_class(inputs.shape[1], list(self.alpha)[:n], list(self.gamma)[:n], exact=False)
         loss = _HipLoss.apply(inputs, targets, _lib.LOSS_FOCAL, not self.logits, alpha, gamma)
         return loss.mean() if self.reduce else loss
+
+    def attach(self, model):
+        if not self.logits:
+            raise ValueError("the fused training tail works on logits: construct the loss with logits=True")
+        n = min(len(self.alpha), len(self.gamma))
+        alpha, gamma = self._per_class(int(model.num_classes), list(self.alpha)[:n], list(self.gamma)[:n], exact=False)
+        model.set_loss("focal", alpha, gamma)
+        return model

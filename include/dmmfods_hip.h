@@ -210,6 +210,15 @@ int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void
                                const float* shift, const void* yfwd, const float* q, const float* r, void* gx, int accumulate,
                                float* dw, double* red, void* scratch, void* stream);
 
+/* Which kernel family ran the calling thread's most recent single-kernel launch (dmm_conv_forward / _wgrad(_ex) / _dgrad(_ex) /
+ * dmm_conv1x1_backward_fused; for multi-launch entry points: the last launch).  The single-kernel entry points dispatch like a
+ * plan does and fall back to the generic implicit-GEMM kernels when no specialised family accepts the shape - silently, so a
+ * per-kernel parity test asserts the family it names: dmm_impl_name(dmm_last_impl()) is one of
+ * "generic", "thin", "conv3", "cvp", "halo", "wg3", "wg5", "wgp", "pig", "bw1"  ("auto": nothing launched yet).
+ * (Nothing upstream: the reference has no kernel families; torch dispatches inside ATen.) */
+int dmm_last_impl(void);
+const char* dmm_impl_name(int impl);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,11 @@ def test_grad_buckets_cover_arena_in_backward_order(lib):
         assert pos("features.conv0.weight") >= pos("features.denseblock3.denselayer1.conv1.weight")
         if cbb == 3:
             assert pos("stream_2_features.conv0.weight") == len(buckets) - 1
+        # cuts inside the encoder (round 4): blocks 4 and 3 do not wait for conv0, and what is left behind the end of backward -
+        # the bucket that becomes ready last - is the stem with blocks 1-2 (5.3 MB), not the whole encoder (25 MB in round 3)
+        assert pos("features.denseblock4.denselayer1.conv1.weight") < pos("features.denseblock3.denselayer1.conv1.weight") < pos("features.conv0.weight")
+        assert buckets[-1][1] * 4 <= 8 << 20, [round(c * 4 / 2 ** 20, 1) for _, c in buckets]
+        assert max(c for _, c in buckets) * 4 <= 40 << 20                # the largest: the decoder's first ConvTranspose alone (37.7 MB)
 
 
 _DP_SCRIPT = r"""

@@ -281,6 +281,11 @@ def test_thin_logits_kernel_matches_generic_kernels():
     from dmmfods_amd.graphs.models.Dense_U_Net_lidar import densenet121_u_lidar
     from dmmfods_amd.utils.Dense_U_Net_lidar_helper import get_config
     cfg = get_config("/tmp/none")
+    # The weights are seeded HERE: with the process-wide generator in whatever state the tests before left it, the difference
+    # between the two summation orders ranged over 1.0e-5 ... 8.7e-5 of max|logit| across three seeds (tools/probes/thin_flaky.py,
+    # round 4; the forward itself is bit-reproducible: thin/thin and generic/generic pairs differ by exactly 0) and one driver run
+    # drew 1.06e-4 against the old bound of 1e-4.  1600 fp32 products per logit with heavy cancellation: the bound is 3e-4.
+    torch.manual_seed(5)
     model = densenet121_u_lidar(config=cfg, compute_dtype="fp16").cuda().train()
     g = torch.Generator().manual_seed(5)
     for (H, W) in ((64, 96), (160, 288)):      # one x strip / three x strips with a ragged last one, several y strips
@@ -296,7 +301,7 @@ def test_thin_logits_kernel_matches_generic_kernels():
         model._plans.clear()
         scale = float(out[0].abs().max())
         assert scale > 0 and torch.isfinite(out[1]).all()
-        assert float((out[1] - out[0]).abs().max()) <= 1e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
+        assert float((out[1] - out[0]).abs().max()) <= 3e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
     with pytest.raises(ValueError):
         _lib.check(_lib.lib().dmm_set_option(b"no_such_option", 1))
 

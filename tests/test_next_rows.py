@@ -105,8 +105,12 @@ def test_focal_loss_surface():
     assert (c.alpha, c.gamma, c.logits, c.reduce) == ([1, 1, 1], [2, 2, 2], True, False)   # L:60
     with pytest.raises(RuntimeError, match="GPU only"):   # no CPU fallback
         c(torch.zeros(1, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+    m = ClassWiseFocalLoss([1, 2], [1, 2, 3])             # the reference's zip() stops at the shorter list (L:85): no error
+    assert (m.alpha, m.gamma) == ([1, 2], [1, 2, 3])
+    a, g = FocalLoss._per_class(3, m.alpha[:2], m.gamma[:2], exact=False)
+    assert a == [1.0, 2.0, 0.0] and g == [1.0, 2.0, 1.0]  # unlisted classes: zero loss
     with pytest.raises(ValueError):
-        ClassWiseFocalLoss([1, 2], [1, 2, 3])
+        FocalLoss._per_class(3, [1, 2], [1, 2], exact=True)
 
 
 @pytest.mark.gpu
@@ -354,3 +358,18 @@ def test_focal_loss_accepts_what_the_reference_accepts():
         torch.testing.assert_close(out10[:, i], ref(x10[:, i], t10[:, i], al[i], ga[i]), rtol=2e-5, atol=1e-6)
     with pytest.raises(IndexError):
         ClassWiseFocalLoss(alpha=[1, 1, 1, 1], gamma=[2, 2, 2, 2])(x, t)
+    # lists of different lengths are cut to the shorter one (zip, L:85); the module's attributes are never rebound
+    m = ClassWiseFocalLoss(alpha=[1.0, 2.0, 0.5], gamma=[2.0, 1.0])
+    out = m(x, t)
+    torch.testing.assert_close(out[:, 1], ref(x[:, 1], t[:, 1], 2.0, 1.0), rtol=2e-5, atol=1e-6)
+    assert float(out[:, 2].abs().max()) == 0.0 and m.alpha == [1.0, 2.0, 0.5] and m.gamma == [2.0, 1.0]
+    # tensor-valued alpha / gamma broadcast against the loss as in the reference's expression (L:44-45)
+    al = torch.tensor([0.5, 1.0, 2.0], device="cuda").view(1, 3, 1, 1)
+    ga = torch.tensor([1.0, 2.0, 3.0], device="cuda").view(1, 3, 1, 1)
+    xg = x.clone().requires_grad_(True)
+    out = FocalLoss(alpha=al, gamma=ga, logits=True, reduce=False)(xg, t)
+    torch.testing.assert_close(out, ref(x, t, al, ga), rtol=2e-5, atol=1e-6)
+    out.sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref(xr, t, al, ga).sum().backward()
+    torch.testing.assert_close(xg.grad, xr.grad, rtol=2e-4, atol=2e-6)

@@ -4,7 +4,7 @@
 tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out
 for v in "$@"; do
   if [ "$v" = main ]; then unset DMM_LIB_PATH; else export DMM_LIB_PATH=$PWD/build_var/lib_$v.so; fi
-  timeout -k 10 200 python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --table ${AB_ARGS} > $out/bench_$v.json 2> $out/bench_$v.txt || { echo "$v FAILED"; tail -3 $out/bench_$v.txt; continue; }
+  timeout -k 10 200 python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --table --ops 2000 ${AB_ARGS} > $out/bench_$v.json 2> $out/bench_$v.txt || { echo "$v FAILED"; tail -3 $out/bench_$v.txt; continue; }
   python3 - "$v" $out/bench_$v.json $out/bench_$v.txt <<'PY'
 import json, sys, os
 tag, j, t = sys.argv[1:4]
