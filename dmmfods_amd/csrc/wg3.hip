@@ -64,6 +64,56 @@ __device__ __forceinline__ typename TT<T>::vec w3_frag(const w3_u32x2& lo, const
 // one barrier per tile for all eight waves: the wave's own LDS traffic has returned; vector-memory requests stay in flight
 __device__ __forceinline__ void w3_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The loaders' global loads and their waits are INLINE ASSEMBLY.  Written as plain C++ loads hipcc counted them itself and, at the
+// header of the two-set loop, waited vmcnt(13) ... vmcnt(0) for the OLDER of two register sets in flight (27 ... 14 would do): its
+// merged wait-count state dropped the newer set, every other tile drained the whole ring, and the kernel ran no faster than the
+// four-wave one (ISA of the first version, round 4).  From assembly the compiler counts nothing: a loader wave's only vector-memory
+// operations are these loads, issued set by set in program order, so "all but the newest NLD have returned" is exactly "the older set
+// has landed".  Data flow is explicit - the load defines the register, the wait takes every register of the set as a read-write
+// operand, the prologue reads the wait's outputs - so nothing can be scheduled across; tools/check_asm_loads.py checks in the
+// disassembly that no instruction reads a loaded register between its load and its wait.
+template <typename V>
+__device__ __forceinline__ void w3_load(V& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+template <typename T, int NA, int NY, int PQ>
+__device__ __forceinline__ void w3_wait(typename TT<T>::vec (&ra)[NA], typename TT<T>::vec (&ry)[NY], typename TT<T>::vec (&ry2)[PQ == 2 ? NY : 1]) {
+  static_assert(NA == 8 && NY == 3, "operand list below");
+  if constexpr (PQ == 2)
+    asm volatile("s_waitcnt vmcnt(14)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                   "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]), "+v"(ry2[0]), "+v"(ry2[1]), "+v"(ry2[2]));
+  else
+    asm volatile("s_waitcnt vmcnt(11)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                   "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]));
+}
+
+// keeps a register set alive (operands) up to this point; DRAIN: and waits for every request in flight
+template <typename T, int NA, int NY, int PQ, bool DRAIN>
+__device__ __forceinline__ void w3_hold(typename TT<T>::vec (&ra)[NA], typename TT<T>::vec (&ry)[NY], typename TT<T>::vec (&ry2)[PQ == 2 ? NY : 1]) {
+  static_assert(NA == 8 && NY == 3, "operand list below");
+  if constexpr (DRAIN) {
+    if constexpr (PQ == 2)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                     "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]), "+v"(ry2[0]), "+v"(ry2[1]), "+v"(ry2[2]));
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                     "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]));
+  } else {
+    if constexpr (PQ == 2)
+      asm volatile("; hold"
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                     "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]), "+v"(ry2[0]), "+v"(ry2[1]), "+v"(ry2[2]));
+    else
+      asm volatile("; hold"
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                     "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]));
+  }
+}
+
 // PQ = prologue of dY: 0 none (materialised gradient), 2 effective gradient (q, r of the 16-bit form)
 template <typename T, int PQ>
 __global__ __launch_bounds__(W3_NT, 1) void wg3_kernel(const Wg3Args g) {
@@ -119,7 +169,7 @@ __global__ __launch_bounds__(W3_NT, 1) void wg3_kernel(const Wg3Args g) {
         const int y = y0 + i;
         if (y < a.Ho && xa < a.Wo) R.oka |= 1u << i;
         const size_t pix = (arow + min(y, sa.Hs - 1)) * sa.Ws + min(xa, sa.Ws - 1);
-        if (!(WG3_DBG & 4)) R.ra[i] = *(const V*)(asrc + pix * sa.ld);
+        if (!(WG3_DBG & 4)) w3_load(R.ra[i], asrc + pix * sa.ld);
       }
       const size_t yrow = (size_t)cb * sy_.Hs;
 #pragma unroll
@@ -127,14 +177,15 @@ __global__ __launch_bounds__(W3_NT, 1) void wg3_kernel(const Wg3Args g) {
         const int y = y0 + hyy[i], x = x0 + hxx[i];
         if (hy0 + 64 * i < W3_HH * W3_HW && (unsigned)y < (unsigned)sy_.Hs && (unsigned)x < (unsigned)sy_.Ws) R.oky |= 1u << i;
         const size_t pix = (yrow + min(max(y, 0), sy_.Hs - 1)) * sy_.Ws + min(max(x, 0), sy_.Ws - 1);
-        if (!(WG3_DBG & 4)) R.ry[i] = *(const V*)(ysrc + pix * sy_.ld);
-        if constexpr (PQ == 2) { if (!(WG3_DBG & 4)) R.ry2[i] = *(const V*)(ysrc2 + pix * sy_.ld2); }
+        if (!(WG3_DBG & 4)) w3_load(R.ry[i], ysrc + pix * sy_.ld);
+        if constexpr (PQ == 2) { if (!(WG3_DBG & 4)) w3_load(R.ry2[i], ysrc2 + pix * sy_.ld2); }
       }
       if (--cleft > 0) {  // (uniform) advance; the cursor parks on the last tile
         if (++ctx == g.tiles_x) { ctx = 0; if (++cty == g.tiles_y) { cty = 0; ++cb; } }
       }
     };
-    auto store = [&](const LSet& R, int set) {
+    auto store = [&](LSet& R, int set, bool wait = true) {
+      if (wait && !(WG3_DBG & 4)) w3_wait<T, NA, NY, PQ>(R.ra, R.ry, R.ry2);  // this set has landed; the other set's NLD requests stay in flight
       unsigned char* As = smem + set * W3_IMG;
       unsigned char* Ys = As + W3_A_BYTES;
       V z;
@@ -156,17 +207,39 @@ __global__ __launch_bounds__(W3_NT, 1) void wg3_kernel(const Wg3Args g) {
         }
       }
     };
+    // The prologue constants must have ARRIVED before the ring starts: loaded in front of it and first used inside the loop they stay
+    // "pending" in hipcc's wait-count model on the loop's entry path, the merged state at the loop header then waits for them in EVERY
+    // iteration - with the ring's loads issued behind them that wait was vmcnt(13) ... vmcnt(0): it drained the second register set
+    // (seen in the ISA of the first version of this kernel: no gain over the four-wave kernel until this was fixed).
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) {
+      asm volatile("" : "+v"(ka.k0[e]), "+v"(ka.k1[e]));
+      if constexpr (PQ == 2) asm volatile("" : "+v"(ky.k0[e]), "+v"(ky.k1[e]));
+    }
     LSet R0, R1;
     issue(R0);
     issue(R1);
-    for (int k = 0; k < nt; k += 2) {
-      store(R0, 0);   // waits for R0's loads only (the compiler counts: R1's stay in flight)
+    // (both halves unconditional in the loop, the odd last tile behind it: with a break in the middle the compiled loop has a path
+    // from the first half straight to the latch, which tools/check_asm_loads.py - it cannot know that path always leaves - must flag)
+    for (int k = 0; k + 1 < nt; k += 2) {
+      store(R0, 0);   // waits for R0's loads only: R1's stay in flight
       w3_bar();       // barrier k: image 0 complete / the matrix waves have left image 1
       issue(R0);      // tile k + 2
-      if (k + 1 >= nt) break;
       store(R1, 1);
       w3_bar();       // barrier k + 1
       issue(R1);      // tile k + 3
+    }
+    // Behind the loop BOTH sets may still have requests in flight (the cursor's surplus requests for tiles past the end), and the
+    // compiler - which does not know that - considers a set's registers free from its last use on: it reused R1's registers as
+    // temporaries of the odd tile's prologue below while R1's loads were still landing in them (found by tools/check_asm_loads.py
+    // before the first run).  So: everything lands HERE, and both sets are operands of the statements, i.e. alive until then.
+    if (!(WG3_DBG & 4)) {
+      w3_hold<T, NA, NY, PQ, true>(R0.ra, R0.ry, R0.ry2);
+      w3_hold<T, NA, NY, PQ, false>(R1.ra, R1.ry, R1.ry2);
+    }
+    if (nt & 1) {
+      store(R0, 0, false);
+      w3_bar();
     }
     return;
   }
@@ -209,32 +282,42 @@ __global__ __launch_bounds__(W3_NT, 1) void wg3_kernel(const Wg3Args g) {
     }
   }
 
-  // ---- the partial result dP[chunk = tap][c][n]: to this workgroup's slot (plain stores) or added to the packed gradient ----
+  // ---- the partial result: to this workgroup's slot (plain 16-byte stores) or added to the packed gradient dP[tap][c][n] ----
+  // Slot layout = the accumulator layout: float4 j of tap t of wave w of lane l at (((t * 4 + w) * 4 + j) * 64 + l) * 4, i.e. every
+  // store instruction writes 1 KB contiguous (36 per lane instead of 144 scalar ones); wg3_reduce_kernel knows the permutation.
   const int r = lane & 31, h = lane >> 5;
-  float* slot = g.part ? g.part + (size_t)blockIdx.x * W3_SLOT_FLOATS : nullptr;
+  if (g.part != nullptr) {
+    f32x4* slot = (f32x4*)(g.part + (size_t)blockIdx.x * W3_SLOT_FLOATS);
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-      const size_t e = ((size_t)t * W3_CA + c) * 32 + r;
-      if (!(WG3_DBG & 1) || acc[t][i] == 1.2345e33f) {
-        if (slot) slot[e] = acc[t][i];
-        else atomic_add_f32(a.dpack + ((size_t)t * a.Npad + c) * 32 + r, acc[t][i]);
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = {acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]};
+        if (!(WG3_DBG & 1) || v[0] == 1.2345e33f) slot[((t * 4 + wave) * 4 + j) * 64 + lane] = v;
       }
-    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (!(WG3_DBG & 1) || acc[t][i] == 1.2345e33f) atomic_add_f32(a.dpack + ((size_t)t * a.Npad + c) * 32 + r, acc[t][i]);
+      }
+  }
 }
 
-// dpack[e] += sum of the slots, in a fixed order (no float atomics).  288 workgroups: thread (o, sg) adds the slots sg, sg + 8, ... of four
-// consecutive floats - all its loads are independent and in flight together - and the eight partial sums of an output are added
-// through LDS in the order sg = 0..7.  (First version: one thread per output walking ALL slots, 36 workgroups: 19 dependent rounds
-// of loads, ~35 us per launch - more than the weight-gradient kernel itself on blocks 3-4.)
+// dpack += sum of the slots, in a fixed order (no float atomics).  288 workgroups: thread (o, sg) adds the slots sg, sg + 8, ... of one
+// float4 of the slot layout - all its loads are independent and in flight together - and the eight partial sums are added through
+// LDS in the order sg = 0..7.  (First version: one thread per output walking ALL slots, 36 workgroups: 19 dependent rounds of
+// loads, ~35 us per launch - more than the weight-gradient kernel itself on blocks 3-4.)
+// float4 f of a slot = (tap t, wave w, quad j, lane l): accumulator elements 4j .. 4j+3 = channels 32 w + 8 j + 4 (l >> 5) + 0..3 of
+// column n = l & 31 (the 32x32 MFMA result layout), i.e. four dP rows 128 bytes apart.
 constexpr int W3_RG = 8;  // slot groups
 __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dpack, int nslots) {
   __shared__ f32x4 red[W3_RG][32];
   const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int e = (blockIdx.x * 32 + o) * 4;
-  const float* p = part + e;
+  const int f = blockIdx.x * 32 + o;
+  const float* p = part + (size_t)f * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int k = sg;
   for (; k + 3 * W3_RG < nslots; k += 4 * W3_RG) {
@@ -248,10 +331,13 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
   red[sg][o] = s;
   __syncthreads();
   if (sg == 0) {
-    f32x4 t = red[0][o];
+    f32x4 t4 = red[0][o];
 #pragma unroll
-    for (int g2 = 1; g2 < W3_RG; ++g2) t += red[g2][o];
-    *(f32x4*)(dpack + e) += t;
+    for (int g2 = 1; g2 < W3_RG; ++g2) t4 += red[g2][o];
+    const int l = f & 63, j = (f >> 6) & 3, w = (f >> 8) & 3, t = f >> 10;
+    float* d = dpack + ((size_t)t * W3_CA + 32 * w + 8 * j + 4 * (l >> 5)) * 32 + (l & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q * 32] += t4[q];
   }
 }
 

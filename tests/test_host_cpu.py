@@ -301,3 +301,20 @@ def test_grad_allreduce_real_size_arena_gloo_world2(lib, tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_inline_assembly_loads_are_waited_for_before_use():
+    """wg3.hip's loader waves issue their global loads and the matching vmcnt waits from inline assembly (hipcc's own wait counting
+    drained the second register set: see the comment in the kernel).  Nothing but the hand-written wait then orders a use behind the
+    arrival of the data, so the ISA is checked: tools/check_asm_loads.py follows every path of the compiled kernel with the queue of
+    loads in flight and fails if any instruction touches a register whose load has not been retired by a wait."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_loads.py"),
+                        os.path.join(root, "dmmfods_amd", "csrc", "wg3.hip"), "wg3_kernel"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 violations") == 4, r.stdout     # f16 / bf16 x effective-gradient / materialised
