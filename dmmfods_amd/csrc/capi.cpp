@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <chrono>
 #include <string>
 
 #include "plan.h"
@@ -186,9 +187,16 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       forked = false;
     }
   };
+  // DMM_HOST_PROF=1: host time of the enqueue calls by op kind, printed when a list has run 20 times (tools/host_bound.py)
+  static const bool host_prof = getenv("DMM_HOST_PROF") != nullptr;
+  static double hp_launch[32] = {0}, hp_fork[32] = {0};
+  static long hp_n[32] = {0}, hp_lists = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (size_t i = begin; i < end; ++i) {
     Op& o = ops[i];
     hipError_t e = hipSuccess;
+    const double hp_t0 = host_prof ? now() : 0.0;
+    double hp_t1 = hp_t0;
     // side-stream launches: weight gradients and the leaves of the backward graph (stem, raw-input branches)
     hipStream_t lst = st;
     if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
@@ -202,6 +210,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       hipEventRecord(fe, st);
       hipStreamWaitEvent(lst, fe, 0);
       forked = true;
+      if (host_prof) hp_t1 = now();
     }
     const bool sel = selected(o);
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], lst);
@@ -224,6 +233,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, lst); break;
       default: join(); return fail(DMM_ERR_STATE, "unknown op");
     }
+    if (host_prof && o.kind < 32) { const double t2 = now(); hp_fork[o.kind] += hp_t1 - hp_t0; hp_launch[o.kind] += t2 - hp_t1; hp_n[o.kind]++; }
     if (e != hipSuccess) join();  // leave the main stream ordered after whatever the side stream already got
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], lst);
@@ -237,6 +247,14 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     }
   }
   join();
+  if (host_prof && ++hp_lists == 40) {
+    double tot = 0;
+    for (int k = 0; k < 32; ++k) tot += hp_launch[k] + hp_fork[k];
+    fprintf(stderr, "[host] 40 lists: %.2f ms of enqueue calls per list pair\n", tot / 20 / 1e3);
+    for (int k = 0; k < 32; ++k)
+      if (hp_n[k]) fprintf(stderr, "[host] op kind %2d: %6ld calls per pair, launch %.2f us each, fork events %.2f us each\n", k, hp_n[k] / 20,
+                           hp_launch[k] / hp_n[k], hp_fork[k] / hp_n[k]);
+  }
   return DMM_OK;
 }
 

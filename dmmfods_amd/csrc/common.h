@@ -100,6 +100,10 @@ struct ConvArgs {
   // 8 XCDs never meet on a line and each address sees 1/8 of the traffic.  The finalize kernels add the replicas up.
   int stat_stride;
   int pool2;       // each row is a 2x2-average-pooled pixel: distribute 0.25*acc to the 4 source pixels
+  // conv3.hip, data gradient of the dense 3x3 convolution: the gathered operand AFTER its prologue (the effective output gradient of
+  // the 32 growth channels), interior pixels of every tile, as a compact [pixel][32] tensor (nullable).  wg3.hip reads it instead
+  // of gathering 64 bytes per pixel from two [pixel][ld] tensors - the L2 fetches 128-byte lines, so those gathers moved 4x the bytes.
+  void* eff_out;
 };
 
 // Weight-gradient GEMM:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k], same A gather as the forward conv.

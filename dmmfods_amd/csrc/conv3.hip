@@ -278,6 +278,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first two weight groups (issued first) and every load after them
   __syncthreads();                                   // images + first two ring slots complete
+  if constexpr (EPI == EPI_BNBWD && SEG0 && !SEG1 && CS == 4 && SPAN == 2) {
+    // the dense 3x3 convolution's data gradient: hand the effective output gradient of this tile (prologue applied, 16-bit) to the
+    // weight-gradient kernel as a compact [pixel][32] tensor; the stores fly under the K loop
+    if (a.eff_out != nullptr) {
+      T* eo = (T*)a.eff_out;
+#pragma unroll
+      for (int i = 0; i < BM * CS / NTHREADS; ++i) {
+        const int sidx = tid + NTHREADS * i, px = sidx / CS, c4 = sidx % CS;
+        const int py_ = px / C3_TW, px_ = px % C3_TW;
+        const int y = y0 + py_, x = x0 + px_;
+        const V v = *(const V*)(halo + (py_ - g.dymin0) * RP + (px_ - g.dxmin0) * PP + c4 * 16);
+        if (y < a.Ho && x < a.Wo) *(V*)(eo + ((size_t)(b * a.Ho + y) * a.Wo + x) * (CS * SLOT) + c4 * SLOT) = v;
+      }
+    }
+  }
 
   f32x16 acc[NT];
 #pragma unroll

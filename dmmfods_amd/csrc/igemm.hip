@@ -14,6 +14,18 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef IGEMM_FOLD_EPI   // bisect switches of the experiment build below: restrict it to one epilogue / column tile / LIN / PRO
+#define IGEMM_FOLD_EPI -1
+#endif
+#ifndef IGEMM_FOLD_BN
+#define IGEMM_FOLD_BN 0
+#endif
+#ifndef IGEMM_FOLD_LIN
+#define IGEMM_FOLD_LIN -1
+#endif
+#ifndef IGEMM_FOLD_PRO
+#define IGEMM_FOLD_PRO -2
+#endif
 #ifndef IGEMM_F32_FOLD
 #define IGEMM_F32_FOLD 0  // experiment builds only: the lane-swap fold in the fp32 instantiations too (see the comment at the fold)
 #endif
@@ -608,7 +620,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const ConvArgs a) {
   // ---- per-channel reductions: threads -> LDS -> one fp64 atomic per channel per workgroup ----
   // lanes l, l + NCV, l + 2 NCV, ... of a wave hold the same slot column: fold them with cross-lane adds first, so that one
   // lane per column and wave touches LDS (4-way instead of 16..64-way contention on every fp64 LDS atomic)
-  if constexpr ((sizeof(T) == 4 || !MFMA) && !IGEMM_F32_FOLD) {  // (the scalar bring-up kernels of f16 spill as heavily as fp32's)
+  constexpr bool F32FOLD = IGEMM_F32_FOLD && (IGEMM_FOLD_EPI < 0 || EPI == IGEMM_FOLD_EPI) && (IGEMM_FOLD_BN == 0 || BN == IGEMM_FOLD_BN) &&
+                           (IGEMM_FOLD_LIN < 0 || (int)LIN == IGEMM_FOLD_LIN) && (IGEMM_FOLD_PRO < -1 || PRO == IGEMM_FOLD_PRO);
+  if constexpr ((sizeof(T) == 4 || !MFMA) && !F32FOLD) {  // (the scalar bring-up kernels of f16 spill as heavily as fp32's)
     // fp32 storage (the parity mode) keeps the round-2 form.  With fold_to_lds (experiment build -DIGEMM_F32_FOLD=1) two fp32
     // instantiations returned wrong results although the helper alone (tools/probes/fold_probe.hip), every 16-bit kernel and the
     // other fp32 kernels are right: the scalar bring-up kernels (~300 spilled registers) stored rows 25 and 29 of every 32 - the

@@ -623,6 +623,18 @@ struct Builder {
       s.ntaps = 1; s.nchunks = 1;
       s.taps[0] = (short)((py & 0xff) | ((px & 0xff) << 8));
     };
+    // The dense 3x3 convolution in 16-bit storage: its data gradient (conv3.hip) holds the effective output gradient of every tile in
+    // LDS and writes the interior out as a compact [pixel][32] tensor, which the weight gradient (wg3.hip) reads INSTEAD of gathering
+    // 64 of every row's bytes from the block's gradient and activation buffers (128-byte lines: 4x the bytes).  One buffer per
+    // convolution: the weight gradient runs on the other stream, later than the next layer's data gradient.  Reserved by the
+    // shape alone (the sizing pass and the bound pass must take the same bytes); the weight-gradient launch then FOLLOWS the data
+    // gradient in the list.
+    void* eff_compact = nullptr;
+    bool wt_deferred = false;
+    Op wt_op;
+    if (c.wgrad_transposed && dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.nseg == 1 && c.seg[0].C == 128 &&
+        c.seg[0].dgrad == DG_FLIP && getenv("DMM_NO_EFF_COMPACT") == nullptr)
+      eff_compact = wptr<uint8_t>((size_t)c.B * c.Ho * c.Wo * 32 * esz);
     if (c.wgrad_transposed) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;
@@ -645,6 +657,11 @@ struct Builder {
       o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
       tag(o, ncls(o.impl == IMPL_WG3 ? "wg3" : (o.impl == IMPL_WG5 ? "wg5" : "wgradT"), pd.Npad, cb), short_name(c.wname), conv_flops(c, 1),
           src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + w_bytes(c) * 4.0 / esz);
+      if (eff_compact != nullptr && o.impl == IMPL_WG3 && !leaf_scope) {  // emitted behind the data gradient, reading its compact copy
+        wt_op = o;
+        ops->pop_back();
+        wt_deferred = true;
+      }
     } else {
     // The head's first convolution (two segments, four output-parity phases): the phase split exists for the upsampled decoder
     // segment; the 8-channel raw-input segment is a plain 3x3 convolution over the full-resolution grid, whose weight gradient is ONE
@@ -705,7 +722,7 @@ struct Builder {
       ops->pop_back();
       pending_w = true;
     }
-    if (!pending_w) conv_grad_done(c);
+    if (!pending_w && !wt_deferred) conv_grad_done(c);
     // ---- data gradients with fused BN+ReLU backward ----
     for (int s = 0; s < c.nseg; ++s) {
       SegRec& sr = c.seg[s];
@@ -752,6 +769,12 @@ struct Builder {
         const double segf = conv_flops(c, 1) * ((double)sr.Cw / c.Kin) * (sr.dgrad == DG_UP2 ? 16.0 / 36.0 : 1.0);
         o.impl = igemm_pick(a, dtype, EPI_BNBWD, d.use_mfma != 0);
         const bool c3 = o.impl == IMPL_CONV3, cp = o.impl == IMPL_CVP;
+        if (wt_deferred && c3) {  // hand the effective gradient over: the weight gradient reads the compact copy, no prologue
+          a.eff_out = eff_compact;
+          Seg& q = wt_op.w.seg[0];
+          q.src = eff_compact; q.ld = 32;
+          q.src2 = nullptr; q.ld2 = 0; q.q = q.r = q.ql = q.rl = nullptr;
+        }
         tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : (o.impl == IMPL_HALO ? "halo.bnbwd" : "igemm.bnbwd")), pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
       }
@@ -797,6 +820,7 @@ struct Builder {
       if (!raw) sb.ginit = true;
     }
     if (pending_w) { ops->push_back(saved_w); conv_grad_done(c); pending_w = false; }  // (no data gradient was emitted)
+    if (wt_deferred) { ops->push_back(wt_op); conv_grad_done(c); }
     int done = -1;
     for (int s = 0; s < c.nseg; ++s) {
       const int bn = c.seg[s].bn;

@@ -145,7 +145,7 @@ def _errors(model, logits, met, emu, g_emu, o64, g64):
                 grads=(num / den) ** 0.5, y_grads=(ynum / den) ** 0.5, worst_conv=worst)
 
 
-TIMED_FAMILIES = ("bw1.", "conv3.store", "conv3.bnbwd", "wg3.", "wgp.", "cvp.store", "cvp.bnbwd", "wg5.", "thin.logits")
+TIMED_FAMILIES = ("bw1.", "bw1.reduce", "pig.", "conv3.store", "conv3.bnbwd", "wg3.", "wgp.", "cvp.store", "cvp.bnbwd", "wg5.", "thin.logits")
 
 
 @pytest.mark.parametrize("variant,H,W", [("early", 64, 96), ("early", 128, 192), ("mid3", 64, 96), ("mid3", 128, 192)])
@@ -203,3 +203,44 @@ def test_two_block_net_layer_level_16bit(dtype, storage, tol_log, tol_g):
     print(f"two-block net {dtype}: logits {e['logits']:.3e} (emulation vs fp64 {e['y_logits']:.3e}), loss {e['loss']:.3e}, "
           f"grads rel L2 {e['grads']:.3e} (emulation vs fp64 {e['y_grads']:.3e}), worst conv tensor {e['worst_conv'][0]:.3e} {e['worst_conv'][1]}")
     assert e["logits"] < tol_log and e["loss"] < tol_log and e["grads"] < tol_g, e
+
+
+# ------------------------------------------------------------------------------------------------ (4) the compact effective gradient
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_wg3_reads_the_compact_effective_gradient_bit_for_bit(dtype, monkeypatch):
+    """Round 4: the dense 3x3 convolution's data gradient (conv3.hip) writes the effective output gradient of its tiles - prologue
+    applied, 16-bit - as a compact [pixel][32] tensor and the weight gradient (wg3.hip) reads that instead of gathering and
+    correcting 64 bytes per pixel from two wide buffers.  Same operand values, same summation order (per-workgroup slots added in
+    slot order): with the hand-over switched off (DMM_NO_EFF_COMPACT=1, read when a plan is built) every gradient must be EQUAL."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(2, 2), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
+    B, H, W = 2, 72, 104      # ragged tiles in both directions
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, B, 96, 128, seed=3))
+    rgb, lidar, tgt = rgb[..., :H, :W].contiguous(), lidar[..., :H, :W].contiguous(), tgt[..., :H, :W].contiguous()
+    H32, W32 = 64, 96         # the network wants multiples of 32: crop again (the tile grid of block 1 is 16 x 24 -> ragged in x)
+    rgb, lidar, tgt = rgb[..., :H32, :W32].contiguous(), lidar[..., :H32, :W32].contiguous(), tgt[..., :H32, :W32].contiguous()
+    grads = {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_EFF_COMPACT", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_EFF_COMPACT", raising=False)
+        model._plans.clear()
+        model._tracked_arena.zero_() if hasattr(model, "_tracked_arena") else None
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0])
+        assert sum(lab.startswith("wg3.") for lab in labels) == 4
+        grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_EFF_COMPACT", raising=False)
+    model._plans.clear()
+    for k in grads[0]:
+        if k.endswith("conv2.weight"):    # wg3's results: no float atomics anywhere on their path
+            assert torch.equal(grads[0][k], grads[1][k]), (k, float((grads[0][k] - grads[1][k]).abs().max()))
+        else:                             # (other weight gradients are added with fp32 atomics: equal to their order)
+            assert _rel(grads[0][k], grads[1][k]) < 2e-3, k
+    assert any(float(grads[0][k].abs().max()) > 0 for k in grads[0] if k.endswith("conv2.weight"))

@@ -13,6 +13,8 @@ def main():
             d = (x - y).abs().max().item() / max(y.abs().max().item(), 1e-30)
             if d > 1e-6:
                 print(f"{k:60s} rel diff {d:.3e}")
+            if len(sys.argv) > 4 and sys.argv[4] in k:   # per-channel detail of the named tensors
+                print("   ", [f"{v:.2e}" for v in ((x - y).abs() / max(y.abs().max().item(), 1e-30)).flatten().tolist()[:64]])
         return
     variant, dtype, out = sys.argv[1:4]
     from oracle import restatement as R
@@ -28,6 +30,9 @@ def main():
     d = {"logits": logits.detach().cpu()}
     for k, p in model.named_parameters():
         d["grad/" + k] = p.grad.detach().cpu()
+    for k, v in model.state_dict().items():      # the batch statistics of the forward, as the running statistics show them
+        if k.endswith(("running_mean", "running_var")):
+            d["buf/" + k] = v.detach().cpu()
     torch.save(d, out)
 
 

@@ -9,8 +9,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import CONFIGS, Workload  # noqa: E402
 
+# "c2@64x96": the configuration's network at a small size - the same launch list on a GPU that finishes each launch at once, so
+# the enqueue time is the host's own cost per step (at the full size the host also waits whenever the hardware queue is full)
 for name in sys.argv[1:] or ["c1", "c2"]:
-    w = Workload(dict(CONFIGS[name]), torch.device("cuda", 0), 0, False, False)
+    cfg_name, _, size = name.partition("@")
+    cfg = dict(CONFIGS[cfg_name])
+    if size:
+        cfg["H"], cfg["W"] = (int(v) for v in size.split("x"))
+        cfg["batch"] = 1
+    w = Workload(cfg, torch.device("cuda", 0), 0, False, False)
     for _ in range(5):
         w.step()
     torch.cuda.synchronize()

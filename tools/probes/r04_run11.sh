@@ -1,0 +1,3 @@
+python3 tools/grad_dump.py no fp32 /tmp/a.pt 2>/dev/null
+DMM_LIB_PATH=$PWD/build_var/lib_fb_s32.so python3 tools/grad_dump.py no fp32 /tmp/b.pt 2>/dev/null
+python3 tools/probes/fold_ch.py /tmp/a.pt /tmp/b.pt
