@@ -104,6 +104,11 @@ struct ConvArgs {
   // the 32 growth channels), interior pixels of every tile, as a compact [pixel][32] tensor (nullable).  wg3.hip reads it instead
   // of gathering 64 bytes per pixel from two [pixel][ld] tensors - the L2 fetches 128-byte lines, so those gathers moved 4x the bytes.
   void* eff_out;
+  // EPI_BNBWD, second pass of a two-pass BatchNorm backward (conv3.hip; plan.cpp emit_conv_bwd): the per-channel constants of the
+  // deferred correction are already known, so the kernel stores the FINAL gradient s*dz + q[c] + r[c]*x instead of s*dz (nullable;
+  // red1 / red2 are null in that pass: the reductions were the first pass, which stored nothing).
+  const float* eq;
+  const float* er;
 };
 
 // Weight-gradient GEMM:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k], same A gather as the forward conv.

@@ -405,6 +405,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
       load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
     }
+    // second pass of a two-pass BatchNorm backward (thin-only variants: the logits gradient under the 5x5 head convolution): the
+    // correction constants are final, store s*dz + q + r*x - what apply_corr made of s*dz in a pass of its own (read g, read x, write g)
+    constexpr bool TWO_PASS = !SEG0 && SEG1;
+    const bool fin = TWO_PASS && a.eq != nullptr;   // (workgroup-uniform)
+    float qv[TWO_PASS ? SLOT : 1], rv[TWO_PASS ? SLOT : 1];
+    if constexpr (TWO_PASS) {
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) { qv[e] = 0.f; rv[e] = 0.f; }
+      if (fin && colvalid) { load_f32s<SLOT>(a.eq + n, qv); load_f32s<SLOT>(a.er + n, rv); }
+    }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       if (ppre[i] < 0) continue;
@@ -419,16 +429,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
         s1[e] += dz;
         s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
         gf[e] = ((a.accumulate && gout != nullptr) ? gf[e] : 0.f) + sc[e] * dz;
+        if constexpr (TWO_PASS) gf[e] += fmaf(rv[e], xf[e], qv[e]);   // (zeros unless `fin`)
       }
       if (gout != nullptr) *(V*)(gout + (size_t)ppre[i] * a.ldo + n) = f32_to_vec<T>(gf);
     }
-    // per-channel reductions: lanes -> LDS (fp64) -> one fp64 atomic per channel and workgroup (see igemm.hip)
-    fold_to_lds<NCV, SLOT, BN>(s1, s2, red, cv, colvalid, lane);
-    __syncthreads();
-    if (!(C3_DBG & (16 | 32)) && tid < BN && tid < a.N) {
-      const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-      atomic_add_f64(a.red1 + rep + tid, red[fold_slot<NCV, SLOT>(0, tid)]);
-      atomic_add_f64(a.red2 + rep + tid, red[fold_slot<NCV, SLOT>(1, tid)]);
+    if (a.red1 != nullptr) {  // (workgroup-uniform; null in the second pass of a two-pass BatchNorm backward)
+      // per-channel reductions: lanes -> LDS (fp64) -> one fp64 atomic per channel and workgroup (see igemm.hip)
+      fold_to_lds<NCV, SLOT, BN>(s1, s2, red, cv, colvalid, lane);
+      __syncthreads();
+      if (!(C3_DBG & (16 | 32)) && tid < BN && tid < a.N) {
+        const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+        atomic_add_f64(a.red1 + rep + tid, red[fold_slot<NCV, SLOT>(0, tid)]);
+        atomic_add_f64(a.red2 + rep + tid, red[fold_slot<NCV, SLOT>(1, tid)]);
+      }
     }
   }
   }  // (epilogue)

@@ -432,11 +432,42 @@ struct Builder {
   // which multi-consumer gradients are materialised (q + r*y applied once by applycorr) instead of corrected by every consumer's
   // prologue: 1 the decoder's conv_reduce outputs, 2 the last ConvTranspose's output, 4 refine0's output (A/B knob)
   const int matz_mask = getenv("DMM_MATZ_MASK") ? atoi(getenv("DMM_MATZ_MASK")) : 7;
+  // Deferred weight gradients (round 4).  The head's and the decoder's multi-tap weight gradients (wgp / wg5: 4 ms of work alone)
+  // are the FIRST things backward can start on the weight-gradient stream - and they then run beside the head's and the decoder's
+  // data gradients, the heaviest stretch of the main chain: measured with the launches skipped, they cost 3.2 ms of a 27.8 ms step,
+  // i.e. they were hardly hidden at all, while the encoder's weight gradients (3.6 ms alone) cost 1.2 ms.  Nothing needs them before
+  // their bucket's unpack, so they CAN be held back and enter the list where the main chain reaches the encoder (DMM_DEFER_WGRAD=1;
+  // DMM_DEFER_AT=<substring of a weight name> moves the point): there the main chain is a sequence of small launches (blocks 4-3).
+  // Their operands are final by then and stay so: a weight gradient reads forward activations and the gradient of its convolution's
+  // OUTPUT, which nothing writes after that convolution's own backward has been emitted.
+  // MEASURED (C2, one box): 27.71 ms in the old order, 28.14 deferred to the first encoder convolution, 28.65-28.77 deferred further
+  // (transition 3, block 3, block 2).  The chip is work-conserving: the deferred launches cost their 3 ms wherever they run and the
+  // encoder's own weight gradients then pile up behind them at the end of backward.  OFF by default; kept as a switch and a test.
+  bool defer_scope = false;
+  std::vector<Op> deferred_ops;
+  std::vector<const ConvRec*> deferred_convs;
   Op& push(int kind) {
+    if (defer_scope && kind == OP_WGRAD) {
+      deferred_ops.reserve(256);   // (references returned earlier stay valid: one reservation, far above the ~30 launches held)
+      deferred_ops.emplace_back();
+      deferred_ops.back().kind = kind;
+      deferred_ops.back().leaf = leaf_scope ? 1 : 0;
+      return deferred_ops.back();
+    }
     ops->emplace_back();
     ops->back().kind = kind;
     ops->back().leaf = leaf_scope ? 1 : 0;
     return ops->back();
+  }
+  void flush_deferred() {
+    if (deferred_ops.empty() && deferred_convs.empty()) return;
+    for (auto& o : deferred_ops) ops->push_back(o);
+    deferred_ops.clear();
+    const bool keep = defer_scope;
+    defer_scope = false;
+    for (const ConvRec* c : deferred_convs) conv_grad_done(*c);
+    deferred_convs.clear();
+    defer_scope = keep;
   }
   bool is_raw_input(int buf) const { return buf == in1 || buf == in2 || buf == inH; }
   void tag(Op& o, const char* cls, const std::string& layer, double flops, double bytes) {
@@ -616,6 +647,17 @@ struct Builder {
   }
 
   void emit_conv_bwd(ConvRec& c) {
+    {
+      const bool defer_on = getenv("DMM_DEFER_WGRAD") != nullptr && atoi(getenv("DMM_DEFER_WGRAD")) != 0;   // (read per plan build; OFF by default, see above)
+      const char* defer_at = getenv("DMM_DEFER_AT");
+      const bool late = c.wname.rfind("decoder.", 0) == 0 || c.wname.rfind("dec_out_to_heat_maps.", 0) == 0;
+      const bool flush_here = defer_at ? c.wname.find(defer_at) != std::string::npos : !late;
+      if (flush_here) flush_deferred();
+      // multi-tap convolutions only: the decoder's 1x1 convolutions keep their place (the 128-wide one is fused with its data gradient)
+      defer_scope = defer_on && late && d.use_mfma && dtype != DT_F32 && c.R * c.S > 1 && (deferred_ops.size() + 40 < 256) &&
+                    !(defer_at && flush_here);
+    }
+    struct ScopeEnd { bool& f; ~ScopeEnd() { f = false; } } scope_end{defer_scope};
     const Buf& ob = bufs[c.obuf];
     const int Nst = rup(c.N, 8);  // storage channels of the output gradient
     // ---- weight gradient, one launch per phase ----
@@ -632,6 +674,9 @@ struct Builder {
     void* eff_compact = nullptr;
     bool wt_deferred = false;
     Op wt_op;
+    bool have_second = false;
+    Op second_pass;
+    int second_buf = -1;
     if (c.wgrad_transposed && dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.nseg == 1 && c.seg[0].C == 128 &&
         c.seg[0].dgrad == DG_FLIP && getenv("DMM_NO_EFF_COMPACT") == nullptr)
       eff_compact = wptr<uint8_t>((size_t)c.B * c.Ho * c.Wo * 32 * esz);
@@ -777,6 +822,22 @@ struct Builder {
         }
         tag(o, ncls(c3 ? "conv3.bnbwd" : (cp ? "cvp.bnbwd" : (o.impl == IMPL_HALO ? "halo.bnbwd" : "igemm.bnbwd")), pd.Npad, cb), short_name(c.wname), segf,
             ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c) + srcb * (sb.ginit ? 3.0 : 2.0) + w_bytes(c));
+        // Two-pass BatchNorm backward where the data gradient is cheap to run twice and its result would otherwise be corrected by a
+        // pass of its own (apply_corr: read g, read x, write g).  The head's 5x5 convolution onto the classes: its data gradient
+        // reads the 3-channel logits gradient and, for the ReLU mask, the 64-channel full-resolution activation x.  First pass:
+        // reductions only (nothing stored); finalize (q, r); second pass: the same launch stores the FINAL gradient
+        // s*dz + q + r*x.  Traffic 2 x |x| + |g| instead of |x| + |g| (store) + 2 |g| + |x| (apply_corr).
+        if (c3 && !raw && sb.matz && sb.q && !sb.ginit && !sb.materialized && c.nseg == 1 && c.R == 5 && c.S == 5 && dtype != DT_F32 &&
+            getenv("DMM_NO_TWO_PASS") == nullptr) {
+          second_pass = o;                       // stores; no reductions
+          second_pass.c.red1 = nullptr; second_pass.c.red2 = nullptr;
+          second_pass.c.eq = sb.q + sr.ch0; second_pass.c.er = sb.r + sr.ch0;
+          have_second = true;
+          second_buf = sr.buf;
+          a.out = nullptr;                       // first pass: reductions only
+          o.bytes = out_bytes(c) + srcb + w_bytes(c);          // reads dy and x, writes nothing
+          second_pass.bytes = out_bytes(c) + srcb * 2.0 + w_bytes(c);
+        }
       }
       if (pending_w) {
         pending_w = false;
@@ -822,12 +883,14 @@ struct Builder {
     if (pending_w) { ops->push_back(saved_w); conv_grad_done(c); pending_w = false; }  // (no data gradient was emitted)
     if (wt_deferred) { ops->push_back(wt_op); conv_grad_done(c); }
     int done = -1;
+    if (have_second) bufs[second_buf].materialized = true;   // (no apply_corr behind the finalize: the second pass stores the final gradient)
     for (int s = 0; s < c.nseg; ++s) {
       const int bn = c.seg[s].bn;
       if (bn < 0 || bn == done || c.seg[s].dgrad == DG_NONE) continue;
       emit_bn_bwd_finalize(bn);
       done = bn;
     }
+    if (have_second) ops->push_back(second_pass);
   }
 
   void emit_pool_fwd(PoolRec& p) {
@@ -1241,6 +1304,7 @@ struct Builder {
     if (o.kind == OP_WGRAD || o.kind == OP_UNPACK || o.leaf) brecs[b].last_side = op_index; else brecs[b].last_main = op_index;
   }
   void conv_grad_done(const ConvRec& c) {  // called behind the weight-gradient launch(es) of a convolution
+    if (defer_scope) { deferred_convs.push_back(&c); return; }
     const int b = bucket_of(T(c.wname).off);
     BucketRec& bk = brecs[b];
     if (--bk.convs_left > 0 || bk.ndesc == 0) return;
@@ -1352,6 +1416,7 @@ struct Builder {
     for (int i = (int)recs.size() - 1; i >= 0; --i) {
       if (recs[i].type == 0) emit_conv_bwd(convs[recs[i].idx]); else emit_pool_bwd(pools[recs[i].idx]);
     }
+    flush_deferred();
     finish_buckets();
   }
 };

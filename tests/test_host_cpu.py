@@ -318,3 +318,62 @@ def test_inline_assembly_loads_are_waited_for_before_use():
                         os.path.join(root, "dmmfods_amd", "csrc", "wg3.hip"), "wg3_kernel"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 violations") == 4, r.stdout     # f16 / bf16 x effective-gradient / materialised
+
+
+def test_fold_lane_algebra():
+    """gather.h fold_to_lds (the per-channel reductions of every 16-bit epilogue) emulated lane by lane: v_permlane32_swap /
+    v_permlane16_swap / DPP row_ror semantics as documented there, for every (slot columns, slot width) pair the kernels
+    instantiate - the totals each LDS accumulator receives must be the column sums.  (Round 4: part of running down the round-3
+    'fold anomaly' - the helper's algebra is exact; see the comment at the fold in igemm.hip.)"""
+    import numpy as np
+
+    def swap32(a, b):
+        out = np.empty(64)
+        out[:32] = a[:32] + a[32:]
+        out[32:] = b[:32] + b[32:]
+        return out
+
+    def swap16(a, b):
+        out = np.empty(64)
+        for row in range(4):
+            sl = slice(16 * row, 16 * row + 16)
+            if row % 2 == 0:
+                out[sl] = a[sl] + a[16 * (row + 1):16 * (row + 2)]
+            else:
+                out[sl] = b[16 * (row - 1):16 * row] + b[sl]
+        return out
+
+    def ror(v, n):
+        return np.array([v[(l // 16) * 16 + (l % 16 + n) % 16] for l in range(64)])
+
+    def pick(lane):
+        g = lane >> 4
+        return ((g & 1) << 1) | (g >> 1)
+
+    rng = np.random.default_rng(0)
+    for ncv, slot in [(32, 4), (16, 4), (8, 4), (16, 8), (8, 8), (4, 8)]:
+        s1, s2 = rng.standard_normal((64, slot)), rng.standard_normal((64, slot))
+        red = np.zeros(2 * slot * ncv)
+        v = [s1[:, e].copy() for e in range(slot)] + [s2[:, e].copy() for e in range(slot)]
+        cv = np.arange(64) % ncv
+        if ncv == 32:
+            for k in range(slot):
+                t = swap32(v[2 * k], v[2 * k + 1])
+                for l in range(64):
+                    red[(2 * k + (l >> 5)) * ncv + cv[l]] += t[l]
+        else:
+            if ncv <= 8:
+                v = [x + ror(x, 8) for x in v]
+            if ncv <= 4:
+                v = [x + ror(x, 4) for x in v]
+            for m in range(slot // 2):
+                w = swap16(swap32(v[4 * m], v[4 * m + 1]), swap32(v[4 * m + 2], v[4 * m + 3]))
+                for l in range(64):
+                    if (l & 15) < ncv:
+                        red[(4 * m + pick(l)) * ncv + cv[l]] += w[l]
+        want = np.zeros_like(red)
+        for l in range(64):
+            for e in range(slot):
+                want[e * ncv + l % ncv] += s1[l, e]
+                want[(slot + e) * ncv + l % ncv] += s2[l, e]
+        assert np.abs(red - want).max() < 1e-12, (ncv, slot)

@@ -244,3 +244,73 @@ def test_wg3_reads_the_compact_effective_gradient_bit_for_bit(dtype, monkeypatch
         else:                             # (other weight gradients are added with fp32 atomics: equal to their order)
             assert _rel(grads[0][k], grads[1][k]) < 2e-3, k
     assert any(float(grads[0][k].abs().max()) > 0 for k in grads[0] if k.endswith("conv2.weight"))
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("bf16", 2e-2)])
+def test_two_pass_batchnorm_backward_of_the_head(dtype, tol, monkeypatch):
+    """Round 4: the data gradient of the head's 5x5 convolution runs twice - reductions only, then (the correction constants of the
+    BatchNorm in front of it being final) storing s*dz + q + r*x - instead of once plus an apply_corr pass over the 64-channel
+    full-resolution gradient.  Against the one-pass + apply_corr schedule (DMM_NO_TWO_PASS=1): the same gradients up to ONE 16-bit
+    rounding of that tensor (the old schedule rounds s*dz, then the corrected sum)."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=3))
+    grads, labels = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_TWO_PASS", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_TWO_PASS", raising=False)
+        model._plans.clear()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labels[off] = plan_labels(model._last[0])
+        grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_TWO_PASS", raising=False)
+    model._plans.clear()
+    n_on = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[0])
+    n_off = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[1])
+    assert (n_on, n_off) == (2, 1), (n_on, n_off)
+    assert sum(lab.startswith("applycorr") for lab in labels[0]) == sum(lab.startswith("applycorr") for lab in labels[1]) - 1
+    num = sum(float((grads[0][k].double() - grads[1][k].double()).pow(2).sum()) for k in grads[0])
+    den = sum(float(grads[1][k].double().pow(2).sum()) for k in grads[0])
+    assert (num / den) ** 0.5 < tol, (num / den) ** 0.5
+    for k in grads[0]:
+        assert torch.isfinite(grads[0][k]).all(), k
+
+
+def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
+    """Round 4 experiment, kept as a switch (DMM_DEFER_WGRAD=1; measured slower, plan.cpp): the head's / decoder's multi-tap weight
+    gradients enter the backward list where the main chain reaches the encoder instead of at the front.  Same launches, same
+    operands: against the default order the gradients agree to the order of their fp32 atomics, the launch multiset is the same
+    and the first weight-gradient launch of the head then FOLLOWS the decoder's last data gradient."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, "fp16")
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=3))
+    grads, labels = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
+        else:
+            monkeypatch.setenv("DMM_DEFER_WGRAD", "1")
+        model._plans.clear()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labels[off] = plan_labels(model._last[0])
+        grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
+    model._plans.clear()
+    assert sorted(labels[0]) == sorted(labels[1])
+    first_head_w = {o: next(i for i, lab in enumerate(labels[o]) if lab.startswith(("wgp.", "wg5.")) and "/h." in lab) for o in (0, 1)}
+    last_dec_dgrad = {o: max(i for i, lab in enumerate(labels[o]) if ".bnbwd" in lab and "/d." in lab) for o in (0, 1)}
+    assert first_head_w[0] > last_dec_dgrad[0] and first_head_w[1] < last_dec_dgrad[1], (first_head_w, last_dec_dgrad)
+    for k in grads[0]:
+        assert _rel(grads[0][k], grads[1][k]) < 2e-3, k
