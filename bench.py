@@ -127,6 +127,23 @@ def measured_traffic(cls, workload):
     return None
 
 
+def in_step_kernel_sum(workload):
+    """Sum of all kernel durations per step, both streams, from the committed rocprofv3 --kernel-trace --stats summary of this
+    workload (profiles/*/<config>_b<batch>_kernel_stats.json, written by tools/profile_round.sh next to the CSV; bench.py cannot
+    wrap itself in the profiler)."""
+    import glob
+    import json as _json
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*", "*kernel_stats.json")), reverse=True):
+        try:
+            d = _json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if (d.get("config"), d.get("batch"), d.get("dtype")) == workload and d.get("steps"):
+            return round(d["total_kernel_ms"] / d["steps"], 3), os.path.relpath(path, here)
+    return None
+
+
 def roofline_block(classes, dtype, workload=None, timed=None):
     if not classes:
         return None, None
@@ -421,6 +438,24 @@ def main():
                 "unoverlapped_tail_ms": step_stats(tails)}
     w.tail_events = None
 
+    # The value of the weight-gradient stream as a number (world 1): the same step with every launch on ONE stream, right behind
+    # the timed region.  (dmm_set_option("overlap_wgrad") is read at every launch list; the plan is not rebuilt.)
+    schedule = None
+    timed_classes = None
+    if rank == 0 and not args.no_profile and full_classes:
+        timed_classes = collect_profile(None, plan, args.steps)       # (before anything else runs on the plan)
+    if world == 1 and not args.no_profile and not os.environ.get("DMM_NO_OVERLAP"):
+        _lib.check(L.dmm_plan_profile_begin(plan.handle, 0))          # no event pairs in these steps
+        _lib.check(L.dmm_set_option(b"overlap_wgrad", 0))
+        try:
+            for _ in range(2):
+                w.step()
+            el1, ps1, _ = timed_region(w, 6, False, device)
+        finally:
+            _lib.check(L.dmm_set_option(b"overlap_wgrad", 1))
+        schedule = {"two_stream_ms_per_step": round(elapsed / args.steps * 1e3, 3), "single_stream_ms_per_step": round(el1 / 6 * 1e3, 3),
+                    "single_stream_steps": 6}
+
     also = None
     also_name = args.also or ("c3" if world > 1 and args.config == "c2" else "none")
     if world > 1 and also_name != "none" and also_name != args.config:
@@ -444,7 +479,7 @@ def main():
         value = c["batch"] * world * args.steps / elapsed
         roof, table = (None, None)
         if not args.no_profile and full_classes:
-            timed = collect_profile(None, plan, args.steps)
+            timed = timed_classes
             roof, table = roofline_block(full_classes, c["dtype"], (args.config, c["batch"], DTYPE_LABEL[c["dtype"]]), timed)
             if ops_list:
                 ops_list.sort(reverse=True)
@@ -469,6 +504,15 @@ def main():
             "mfma_only_frac_of_step": round(train_flops_img * value / 1e12 / (world * PEAK_MFMA_TFLOPS[c["dtype"]]), 4),
             "roofline": roof,
         }
+        if schedule is not None:
+            # serial sum: the per-launch event times of the untimed one-stream pass (every launch carries ~4 us of event-pair
+            # overhead); in-step sum: rocprofv3 --kernel-trace --stats of this command, total kernel time / steps, both streams
+            if full_classes:
+                schedule["serial_kernel_sum_ms"] = round(sum(e["ms"] for e in full_classes.values()), 3)
+            ins = in_step_kernel_sum((args.config, c["batch"], DTYPE_LABEL[c["dtype"]]))
+            if ins is not None:
+                schedule["in_step_kernel_sum_ms"], schedule["in_step_source"] = ins
+            out["schedule"] = schedule
         if comm is not None:
             out["comm"] = comm
         if also is not None:

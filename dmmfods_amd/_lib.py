@@ -57,6 +57,8 @@ def lib():
     L.dmm_last_impl.restype = C.c_int
     L.dmm_impl_name.restype = C.c_char_p
     L.dmm_impl_name.argtypes = [C.c_int]
+    L.dmm_impl_mask.restype = C.c_uint
+    L.dmm_impl_mask.argtypes = [C.c_int]
     L.dmm_set_option.restype = C.c_int
     L.dmm_set_option.argtypes = [C.c_char_p, C.c_int]
     L.dmm_plan_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
@@ -111,7 +113,7 @@ EXPORTS = [
     "dmm_plan_loss_metrics", "dmm_plan_num_graph_replays", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
     "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
-    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused", "dmm_last_impl", "dmm_impl_name",
+    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused", "dmm_last_impl", "dmm_impl_name", "dmm_impl_mask",
 ]
 
 
@@ -133,6 +135,13 @@ def last_impl():
     """Name of the kernel family that ran this thread's most recent single-kernel launch ("wg3", "conv3", "generic", ...)."""
     L = lib()
     return L.dmm_impl_name(L.dmm_last_impl()).decode()
+
+
+def impls_since_reset(reset=True):
+    """Names of the kernel families that ran this thread's single-kernel launches since the last reset."""
+    L = lib()
+    m = L.dmm_impl_mask(1 if reset else 0)
+    return {L.dmm_impl_name(i).decode() for i in range(32) if (m >> i) & 1}
 
 
 def stream_ptr():

@@ -442,7 +442,7 @@ hipError_t launch_bw1(const Bw1Args& g0, int dtype, hipStream_t st) {
   const ConvArgs& a = g.c;
   if (a.M <= 0) return hipSuccess;
   const Bw1Geom q = bw1_geometry(a);
-  g_last_impl = IMPL_BW1;
+  note_impl(IMPL_BW1);
   g.nct = q.nct; g.ntiles = q.ntiles; g.tiles_per_wg = q.tiles_per_wg; g.xcd_group = q.xcd_group; g.nsplit = q.nsplit;
   const int nwg = q.nwg;
   const int pq = a.seg[0].q ? 2 : 0;

@@ -125,6 +125,14 @@ struct WgradArgs {
   // the family - they run in order on one stream and each is followed by its reduction.
   float* part;
   int part_slots;      // capacity of `part` in slots of W3_SLOT_FLOATS
+  // wgp.hip: several output-parity phases of ONE convolution in one launch (nphase = 0: one phase, the fields above).  The phases
+  // share the gathered operand (seg[0] without its taps) and differ in their taps, the parity of the gradient rows and the packed
+  // gradient they add into.  Phase p of a tile range runs beside the other phases of that range on the same XCD, so the operand
+  // is fetched from HBM once and served to the others by that XCD's L2 (four launches swept it four times).
+  int nphase;
+  short ph_xtaps[4][4];   // taps of seg[0] per phase (ntaps each)
+  short ph_ytap[4];       // parity tap of dy per phase
+  float* ph_dpack[4];
 };
 constexpr int W3_SLOT_FLOATS = 9 * 128 * 32;  // one workgroup's partial result of the dense 3x3 weight gradient (147 KB)
 constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at most (device-independent: plans are sized without a GPU)
@@ -142,6 +150,8 @@ extern thread_local LaunchCtl g_ctl;  // (defined in pointwise.hip)
 // The family that took the calling thread's most recent convolution / weight-gradient / fused-backward launch (dmm_last_impl):
 // a per-kernel test asserts the family it names really ran - IMPL_AUTO falls back to the generic kernels silently.
 extern thread_local int g_last_impl;
+extern thread_local unsigned g_impl_mask;  // 1 << family for every launch since the mask was last reset (dmm_impl_mask)
+inline void note_impl(int impl) { g_last_impl = impl; g_impl_mask |= 1u << impl; }
 inline bool family_on(bool enabled, int family) { return g_ctl.impl == IMPL_AUTO ? enabled : g_ctl.impl == family; }
 
 #if defined(__HIPCC__)

@@ -815,9 +815,9 @@ hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStr
     int took;
     const hipError_t e = dispatch_special(a, dtype, epi, st, took);
     g_ctl = keep;
-    if (e != hipErrorNotSupported) { g_last_impl = took; return e; }
+    if (e != hipErrorNotSupported) { note_impl(took); return e; }
   }
-  g_last_impl = IMPL_GENERIC;
+  note_impl(IMPL_GENERIC);
   if (dtype == DT_F16) return launch_igemm_type<f16>(a, epi, mfma, st);
   if (dtype == DT_BF16) return launch_igemm_type<bf16>(a, epi, mfma, st);
   return launch_igemm_type<float>(a, epi, mfma, st);

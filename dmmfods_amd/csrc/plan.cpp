@@ -737,6 +737,32 @@ struct Builder {
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
+    // Four phases with four taps each, all on wgp.hip (the head's 3x3 over the upsampled decoder output): ONE launch, the phases
+    // of a tile range side by side on one XCD - the half-resolution input (0.8 GB at C2) comes from HBM once instead of four times.
+    if (!defer_scope && c.phases.size() == 4 && wseg == 1 && ops->size() >= 4 && getenv("DMM_NO_WGP_MERGE") == nullptr) {
+      const size_t first = ops->size() - 4;
+      bool ok = true;
+      for (size_t k = first; k < ops->size(); ++k) {
+        const Op& po = (*ops)[k];
+        ok = ok && po.kind == OP_WGRAD && po.impl == IMPL_WGP && po.w.nseg == 1 && po.w.seg[0].ntaps == 4 && po.leaf == (*ops)[first].leaf;
+      }
+      if (ok) {
+        Op merged = (*ops)[first];
+        merged.w.nphase = 4;
+        merged.flops = 0; merged.bytes = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+          const Op& po = (*ops)[first + ph];
+          for (int t = 0; t < 4; ++t) merged.w.ph_xtaps[ph][t] = po.w.seg[0].taps[t];
+          merged.w.ph_ytap[ph] = po.w.dy.taps[0];
+          merged.w.ph_dpack[ph] = po.w.dpack;
+          merged.flops += po.flops; merged.bytes += po.bytes;
+        }
+        if (wgrad_pick(merged.w, dtype, d.use_mfma != 0) == IMPL_WGP) {
+          ops->resize(first);
+          ops->push_back(merged);
+        }
+      }
+    }
     if (raw_once) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;

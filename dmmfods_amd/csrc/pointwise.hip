@@ -14,6 +14,7 @@ namespace dmm {
 
 thread_local LaunchCtl g_ctl;  // see common.h
 thread_local int g_last_impl = IMPL_AUTO;
+thread_local unsigned g_impl_mask = 0;
 
 // ---------------------------------------------------------------------------------------------------
 template <typename T>

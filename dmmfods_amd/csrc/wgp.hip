@@ -33,6 +33,7 @@ struct WgpArgs {
   int tiles_y, tiles_x, ntiles, tiles_per_wg, nsplit;
   int nct, ncot;     // 128-channel tiles of A, NCO-channel tiles of dY
   int dymin, dxmin;  // origin of the tap box
+  int ph_dymin[4], ph_dxmin[4];  // ... per phase of a multi-phase launch (WgradArgs::nphase)
 };
 
 typedef unsigned wp_u32x2 __attribute__((ext_vector_type(2)));
@@ -69,9 +70,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
   unsigned char* Ys = smem + WP_X_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // block -> (split, channel tile of A, channel tile of dY); the tiles of one split are neighbours in the launch order
-  const int pair = blockIdx.x % (g.nct * g.ncot), split = blockIdx.x / (g.nct * g.ncot);
+  // block -> (phase, split, channel tile of A, channel tile of dY); the tiles of one split are neighbours in the launch order.
+  // Several phases in one launch: unit u = (split, pair) of phase ph is workgroup ((u / 8) * nphase + ph) * 8 + u % 8, i.e. the
+  // phases of a unit are dispatched together and - workgroups go to the XCDs round-robin - onto the SAME XCD: they walk the same
+  // tiles at the same pace, the first to ask fetches a halo from HBM and the others find it in that XCD's L2.
+  const int nph = g.w.nphase > 0 ? g.w.nphase : 1;
+  const int slot8 = blockIdx.x >> 3;
+  const int ph = g.w.nphase > 0 ? slot8 % nph : 0;
+  const int unit = g.w.nphase > 0 ? (slot8 / nph) * 8 + (blockIdx.x & 7) : blockIdx.x;
+  if (unit >= g.nsplit * g.nct * g.ncot) return;
+  const int pair = unit % (g.nct * g.ncot), split = unit / (g.nct * g.ncot);
   const int ct = pair % g.nct, cot = pair / g.nct;
+  const int dymin_ = g.w.nphase > 0 ? g.ph_dymin[ph] : g.dymin, dxmin_ = g.w.nphase > 0 ? g.ph_dxmin[ph] : g.dxmin;
+  float* const dpack_ = g.w.nphase > 0 ? g.w.ph_dpack[ph] : g.w.dpack;
   const int t_beg = split * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
   if (t_beg >= t_end) return;
 
@@ -85,7 +96,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
   const T* xsrc = (const T*)sx.src + ct * WP_CA + cx * SLOT;
   const T* ysrc = (const T*)sy.src + cot * NCO + cy * SLOT;
   const T* ysrc2 = (const T*)sy.src2 + cot * NCO + cy * SLOT;
-  const int ypy = (int)(signed char)(sy.taps[0] & 0xff), ypx = (int)(signed char)((sy.taps[0] >> 8) & 0xff);
+  const int ytap_ = g.w.nphase > 0 ? g.w.ph_ytap[ph] : sy.taps[0];
+  const int ypy = (int)(signed char)(ytap_ & 0xff), ypx = (int)(signed char)((ytap_ >> 8) & 0xff);
 
   // per-thread constants of the tile walk: where each of this thread's slots sits relative to the tile origin (global element offset)
   // and in the LDS images, so that an interior tile costs one add per load and nothing per LDS write
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
   auto issue = [&](int tile) {
     const int b = tile / tiles_img, tr = tile - b * tiles_img;
     const int y0 = (tr / g.tiles_x) * WP_TH, x0 = (tr % g.tiles_x) * WP_TW;
-    const int hy0 = y0 + g.dymin, hx0 = x0 + g.dxmin;
+    const int hy0 = y0 + dymin_, hx0 = x0 + dxmin_;
     const bool interior = hy0 >= 0 && hx0 >= 0 && hy0 + WP_HH <= sx.Hs && hx0 + WP_HWR <= sx.Ws && y0 + WP_TH <= a.Ho && x0 + WP_TW <= a.Wo;
     if (interior) {  // (workgroup-uniform) every slot is inside: base + constant offset
       const T* xb = xsrc + ((size_t)(b * sx.Hs + hy0) * sx.Ws + hx0) * sx.ld;
@@ -186,8 +198,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
   int xoff[NTAP];  // byte offset of (tile row 0, pixel arow, tap) in the halo image; the swizzle key (index & 3) is fixed per tap
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
-    const int tw = sx.taps[t];
-    const int dy = (int)(signed char)(tw & 0xff) - g.dymin, dx = (int)(signed char)((tw >> 8) & 0xff) - g.dxmin;
+    const int tw = g.w.nphase > 0 ? g.w.ph_xtaps[ph][t] : sx.taps[t];
+    const int dy = (int)(signed char)(tw & 0xff) - dymin_, dx = (int)(signed char)((tw >> 8) & 0xff) - dxmin_;
     const int idx = dy * WP_HW + arow + dx;
     xoff[t] = idx * 256 + (xcolb ^ ((idx & 3) << 6));
   }
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = cot * NCO + 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h;
-        atomic_add_f32(a.dpack + (chunk * a.Npad + n) * 32 + r, acc[t][j][i]);
+        atomic_add_f32(dpack_ + (chunk * a.Npad + n) * 32 + r, acc[t][j][i]);
       }
   }
 }
@@ -278,20 +290,30 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   if (y.mode != G_PLAIN || y.ntaps != 1 || y.scale != nullptr || (y.istride != 1 && y.istride != 2)) return hipErrorNotSupported;
   if (y.Hs != a.Ho * y.istride || y.Ws != a.Wo * y.istride) return hipErrorNotSupported;
   if (a.N % 64 || a.Npad < a.N || y.C != a.N) return hipErrorNotSupported;
-  int dymin = 127, dxmin = 127, dymax = -128, dxmax = -128;
-  bool seen[4] = {false, false, false, false};
-  for (int t = 0; t < x.ntaps; ++t) {
-    const int dy = (int)(signed char)(x.taps[t] & 0xff), dx = (int)(signed char)((x.taps[t] >> 8) & 0xff);
-    dymin = std::min(dymin, dy); dymax = std::max(dymax, dy); dxmin = std::min(dxmin, dx); dxmax = std::max(dxmax, dx);
+  if (a.nphase < 0 || a.nphase > 4 || (a.nphase > 0 && a.nseg != 1)) return hipErrorNotSupported;
+  int dymin = 127, dxmin = 127;
+  int ph_dymin[4] = {0, 0, 0, 0}, ph_dxmin[4] = {0, 0, 0, 0};
+  for (int ph = 0; ph < std::max(1, a.nphase); ++ph) {   // every phase: taps inside a 2x2 box, each offset once; parity inside the stride
+    const short* taps = a.nphase > 0 ? a.ph_xtaps[ph] : x.taps;
+    int ymin = 127, xmin = 127, ymax = -128, xmax = -128;
+    bool seen[4] = {false, false, false, false};
+    for (int t = 0; t < x.ntaps; ++t) {
+      const int dy = (int)(signed char)(taps[t] & 0xff), dx = (int)(signed char)((taps[t] >> 8) & 0xff);
+      ymin = std::min(ymin, dy); ymax = std::max(ymax, dy); xmin = std::min(xmin, dx); xmax = std::max(xmax, dx);
+    }
+    if (ymax - ymin > 1 || xmax - xmin > 1) return hipErrorNotSupported;
+    for (int t = 0; t < x.ntaps; ++t) {
+      const int dy = (int)(signed char)(taps[t] & 0xff) - ymin, dx = (int)(signed char)((taps[t] >> 8) & 0xff) - xmin;
+      if (seen[dy * 2 + dx]) return hipErrorNotSupported;
+      seen[dy * 2 + dx] = true;
+    }
+    const int yt = a.nphase > 0 ? a.ph_ytap[ph] : y.taps[0];
+    const int py = (int)(signed char)(yt & 0xff), px = (int)(signed char)((yt >> 8) & 0xff);
+    if (py < 0 || px < 0 || py >= y.istride || px >= y.istride) return hipErrorNotSupported;
+    if (a.nphase > 0 && a.ph_dpack[ph] == nullptr) return hipErrorNotSupported;
+    ph_dymin[ph] = ymin; ph_dxmin[ph] = xmin;
+    if (ph == 0) { dymin = ymin; dxmin = xmin; }
   }
-  if (dymax - dymin > 1 || dxmax - dxmin > 1) return hipErrorNotSupported;
-  for (int t = 0; t < x.ntaps; ++t) {
-    const int dy = (int)(signed char)(x.taps[t] & 0xff) - dymin, dx = (int)(signed char)((x.taps[t] >> 8) & 0xff) - dxmin;
-    if (seen[dy * 2 + dx]) return hipErrorNotSupported;
-    seen[dy * 2 + dx] = true;
-  }
-  const int py = (int)(signed char)(y.taps[0] & 0xff), px = (int)(signed char)((y.taps[0] >> 8) & 0xff);
-  if (py < 0 || px < 0 || py >= y.istride || px >= y.istride) return hipErrorNotSupported;
   const int ntap = x.ntaps;
   const int nj = (ntap == 2 && a.N % 128 == 0) ? 4 : 2;
   if (g_ctl.dry) return hipSuccess;
@@ -308,11 +330,15 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   static const int target = getenv("DMM_WGP_WGS") ? atoi(getenv("DMM_WGP_WGS")) : 0;
   const int pairs = g.nct * g.ncot;
-  int nsplit = std::max(1, ((target > 0 ? target : cus) + pairs - 1) / pairs);
+  const int nph = std::max(1, a.nphase);
+  for (int ph = 0; ph < 4; ++ph) { g.ph_dymin[ph] = ph_dymin[ph]; g.ph_dxmin[ph] = ph_dxmin[ph]; }
+  // (multi-phase: the workgroups of all phases together fill the chip once; whole groups of 8 units, see the kernel)
+  int nsplit = std::max(1, ((target > 0 ? target : cus) / nph + pairs - 1) / pairs);
   nsplit = std::min(nsplit, g.ntiles);
   g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
   g.nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
-  const int nwg = g.nsplit * pairs;
+  const int units = g.nsplit * pairs;
+  const int nwg = a.nphase > 0 ? ((units + 7) / 8) * 8 * nph : units;
   const int pq = y.q ? 2 : 0;
   if (trace) fprintf(stderr, "wgp: ntap %d nj %d pq %d pairs %d nsplit %d tiles/wg %d\n", ntap, nj, pq, pairs, g.nsplit, g.tiles_per_wg);
   return dtype == DT_F16 ? launch_wgp_type<f16>(g, ntap, nj, pq, nwg, st) : launch_wgp_type<bf16>(g, ntap, nj, pq, nwg, st);

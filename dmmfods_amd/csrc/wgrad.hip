@@ -458,16 +458,16 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int i
   bool wgp_took = false;
   if (special) {  // the dense layers' 3x3 growth convolution: persistent tiles, the whole result in registers
     const hipError_t e = launch_wg3(a, dtype, st);
-    if (e != hipErrorNotSupported) { g_last_impl = IMPL_WG3; return e; }
+    if (e != hipErrorNotSupported) { note_impl(IMPL_WG3); return e; }
   }
   if (special) {  // the head's 5x5 convolution onto 3 classes: persistent tiles, the 25 x 8 (tap, class) columns as per-lane addresses
     const hipError_t e = launch_wg5(a, dtype, st);
-    if (e != hipErrorNotSupported) { g_last_impl = IMPL_WG5; return e; }
+    if (e != hipErrorNotSupported) { note_impl(IMPL_WG5); return e; }
   }
   if (special) {  // parity-phase convolutions (ConvTranspose stages, the head's 3x3 over the upsampled map): all taps of a phase per tile
     const hipError_t e = launch_wgp(a, dtype, st);
     if (e == hipSuccess) {
-      g_last_impl = IMPL_WGP;
+      note_impl(IMPL_WGP);
       wgp_took = true;
       if (a.nseg == 1) return e;
       // the 8-channel raw-input segment of the head convolution stays with the generic kernel: its chunks follow segment 0's
@@ -477,7 +477,7 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int i
       a.rows_per_split = 0;
     } else if (e != hipErrorNotSupported) return e;
   }
-  if (!wgp_took) g_last_impl = IMPL_GENERIC;  // (wgp for segment 0 + the generic kernel for the raw-input remainder reports wgp)
+  if (!wgp_took) note_impl(IMPL_GENERIC);  // (wgp for segment 0 + the generic kernel for the raw-input remainder reports wgp)
   const int BK = dtype == DT_F32 ? 16 : 32;
   const int bmw = dtype == DT_F32 ? 32 : 64;
   int total = 0;

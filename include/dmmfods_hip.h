@@ -218,6 +218,9 @@ int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void
  * (Nothing upstream: the reference has no kernel families; torch dispatches inside ATen.) */
 int dmm_last_impl(void);
 const char* dmm_impl_name(int impl);
+/* Bit (1 << family) for every such launch of the calling thread since the mask was last reset (entry points that launch several
+ * kernels - the parity phases of a ConvTranspose - leave more than one bit); reset != 0 clears it after reading. */
+unsigned dmm_impl_mask(int reset);
 
 #ifdef __cplusplus
 }

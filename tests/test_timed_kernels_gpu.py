@@ -44,7 +44,7 @@ def test_bw1_fused_backward_of_1x1_bottleneck(lab, dtype, with_q, acc):
     """bw1_kernel<T, PQ, ACC>: every template variant; C_in below / equal to / above one 128-channel slice, a ragged last slice
     (160, 224 = DenseNet-121 block 1), several slices (512), ragged 64-pixel row tiles and a map smaller than one tile."""
     for (B, H, W, Cin) in [(2, 12, 20, 64), (1, 16, 24, 160), (2, 9, 7, 224), (1, 24, 32, 512), (1, 3, 5, 128)]:
-        assert lab.backward_case(f"1x1 {Cin}->128 {B}x{H}x{W}", dtype, B, H, W, Cin, 128, 1, 1, 0, with_q=with_q, acc=acc, what="fused")
+        assert lab.backward_case(f"1x1 {Cin}->128 {B}x{H}x{W}", dtype, B, H, W, Cin, 128, 1, 1, 0, with_q=with_q, acc=acc, what="fused", expect="bw1")
 
 
 @pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
@@ -52,7 +52,7 @@ def test_bw1_fused_backward_of_1x1_bottleneck(lab, dtype, with_q, acc):
 def test_dense_3x3_weight_gradient_transposed_form(lab, dtype, with_q):
     """wg3_kernel<T, PQ> (128 -> 32 channels, the only shape it takes) on ragged 8x16 tiles, one tile, many tiles."""
     for (B, H, W) in [(2, 12, 20), (1, 8, 16), (3, 5, 3), (1, 40, 60)]:
-        assert lab.backward_case(f"3x3 128->32 {B}x{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=with_q, what="wgradT")
+        assert lab.backward_case(f"3x3 128->32 {B}x{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=with_q, what="wgradT", expect="wg3")
 
 
 @pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
@@ -60,23 +60,25 @@ def test_dense_3x3_weight_gradient_transposed_form(lab, dtype, with_q):
 def test_dense_3x3_data_gradient_with_deferred_correction(lab, dtype, with_q, acc):
     """conv3_kernel<..., EPI_BNBWD, PRO=2> (32 -> 128 channels): the production prologue that round 2's per-kernel test never hit."""
     for (B, H, W) in [(2, 12, 20), (1, 8, 16), (2, 7, 9)]:
-        assert lab.backward_case(f"3x3 128->32 {B}x{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=with_q, acc=acc, what="dgrad")
+        assert lab.backward_case(f"3x3 128->32 {B}x{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=with_q, acc=acc, what="dgrad", expect="conv3")
 
 
 @pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
 def test_parity_phase_weight_gradients_with_deferred_correction(lab, dtype):
     """wgp_kernel (ConvTranspose phases) fed the effective gradient, as in the plan's decoder stages."""
     for (B, H, W, Ci, Co) in [(2, 12, 20, 128, 64), (1, 9, 17, 256, 128)]:
-        assert lab.backward_case(f"convT {Ci}->{Co}", dtype, B, H, W, Ci, Co, 3, 3, 1, transposed=1, with_q=1, what="wgrad")
+        assert lab.backward_case(f"convT {Ci}->{Co}", dtype, B, H, W, Ci, Co, 3, 3, 1, transposed=1, with_q=1, what="wgrad", expect="wgp")
 
 
-PRODUCTION = [  # name, B, H, W, Cin, Cout, R, stride, pad, bn, transposed: the launches of BASELINE configs[1] (C2) that run on LDS pipelines
-    ("stem 7x7s2 8->64 @1280x1920", 4, 1280, 1920, 8, 64, 7, 2, 3, 0, 0),
-    ("dense 3x3 128->32 @320x480", 4, 320, 480, 128, 32, 3, 1, 1, 1, 0),
-    ("dense 3x3 128->32 @80x120", 4, 80, 120, 128, 32, 3, 1, 1, 1, 0),
-    ("dense 1x1 224->128 @320x480", 4, 320, 480, 224, 128, 1, 1, 0, 1, 0),
-    ("convT 128->128 @320x480", 4, 320, 480, 128, 128, 3, 2, 1, 1, 1),
-    ("convT 512->512 @80x120", 4, 80, 120, 512, 512, 3, 2, 1, 1, 1),
+PRODUCTION = [  # name, B, H, W, Cin, Cout, R, stride, pad, bn, transposed, family: the launches of BASELINE configs[1] (C2) that run on LDS pipelines
+    ("stem 7x7s2 8->64 @1280x1920", 4, 1280, 1920, 8, 64, 7, 2, 3, 0, 0, "conv3"),
+    ("dense 3x3 128->32 @320x480", 4, 320, 480, 128, 32, 3, 1, 1, 1, 0, "conv3"),
+    ("dense 3x3 128->32 @80x120", 4, 80, 120, 128, 32, 3, 1, 1, 1, 0, "conv3"),
+    ("dense 1x1 224->128 @320x480", 4, 320, 480, 224, 128, 1, 1, 0, 1, 0, "pig"),
+    ("dense 1x1 992->128 @80x120", 4, 80, 120, 992, 128, 1, 1, 0, 1, 0, "pig"),      # K-deep: 16 stages behind counted waits (pig.hip)
+    ("dense 1x1 1024->128 @40x60", 4, 40, 60, 1024, 128, 1, 1, 0, 1, 0, "pig"),     # ... on 75 tiles
+    ("convT 128->128 @320x480", 4, 320, 480, 128, 128, 3, 2, 1, 1, 1, "cvp"),
+    ("convT 512->512 @80x120", 4, 80, 120, 512, 512, 3, 2, 1, 1, 1, "cvp"),
 ]
 
 
@@ -86,7 +88,7 @@ def test_forward_kernels_at_production_size_are_right_and_reproducible(lab, dtyp
     run, none at parity-test sizes: a refill of the weight ring could land before a queued fragment read had executed.  Every LDS
     pipeline on the forward path is therefore also run with the chip full, three times, and must match torch and itself bit for bit."""
     for c in PRODUCTION:
-        assert lab.production_forward_case(c[0], dtype, *c[1:])
+        assert lab.production_forward_case(c[0], dtype, *c[1:-1], expect=c[-1])
 
 
 @pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
@@ -96,12 +98,34 @@ def test_backward_kernels_at_production_size(lab, dtype):
     torch autograd on the GPU, fp32, of the same op on the same 16-bit-rounded operands."""
     B = 4
     for (H, W, Cin) in [(320, 480, 224), (80, 120, 992)]:
-        assert lab.backward_case(f"1x1 {Cin}->128 @{H}x{W}", dtype, B, H, W, Cin, 128, 1, 1, 0, with_q=1, acc=1, what="fused", ref_dev="cuda")
+        assert lab.backward_case(f"1x1 {Cin}->128 @{H}x{W}", dtype, B, H, W, Cin, 128, 1, 1, 0, with_q=1, acc=1, what="fused", ref_dev="cuda", expect="bw1")
     for (H, W) in [(320, 480), (80, 120)]:
-        assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, what="wgradT", ref_dev="cuda")
-        assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, acc=1, what="dgrad", ref_dev="cuda")
-    assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=1, what="wgrad", ref_dev="cuda")
-    assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=0, what="dgrad", ref_dev="cuda")
+        assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, what="wgradT", ref_dev="cuda", expect="wg3")
+        assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, acc=1, what="dgrad", ref_dev="cuda", expect="conv3")
+    assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=1, what="wgrad", ref_dev="cuda", expect="wgp")
+    assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=0, what="dgrad", ref_dev="cuda", expect="cvp")
+    # round 4 (VERDICT 6b): the head's kernels with the chip full - the stride-2 data gradient towards the decoder (cvd<64, true>: the
+    # 3x3 over the nearest-x2 upsampled map, four sub-grids of merged taps) and the 8-channel weight gradients (wg5: the 5x5 onto the
+    # classes in the transposed form, the 3x3 over the raw input in the normal form)
+    assert lab.backward_case("up2 3x3 128->64 @160x240", dtype, 2, 160, 240, 128, 64, 3, 3, 1, mode=1, with_q=0, what="dgrad", ref_dev="cuda", expect="cvp")
+    assert lab.backward_case("5x5 64->3 @320x480", dtype, 2, 320, 480, 64, 3, 5, 5, 2, with_q=0, what="wgradT", ref_dev="cuda", expect="wg5")
+
+
+@pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
+def test_eight_channel_and_upsampled_kernels_against_torch(lab, dtype):
+    """Round 4: wg5.hip's three variants and the head's stride-2 data gradient, each through the C ABI against fp32
+    torch autograd on the same 16-bit-rounded operands at 3e-3 / 2.5e-2 of the tensor's maximum, asserting the family that ran:
+    the 5x5 onto the classes (transposed form, 64 -> 3), the stem's 7x7 stride 2 over the 8-channel raw input (normal form, no
+    BatchNorm in front), the 3x3 over the normalised 8-channel raw input (normal form, 8 -> 64), the 3x3 over the upsampled map."""
+    assert lab.backward_case("5x5 64->3", dtype, 2, 24, 40, 64, 3, 5, 5, 2, with_q=0, what="wgradT", expect="wg5")
+    assert lab.backward_case("5x5 64->3 ragged", dtype, 1, 13, 21, 64, 3, 5, 5, 2, with_q=0, what="wgradT", expect="wg5")
+    assert lab.conv_case("7x7s2 8->64", dtype, 1, 2, 32, 48, 8, 64, 7, 7, 2, 3, bn=0, expect_wgrad="wg5")
+    assert lab.backward_case("3x3 8->64 raw", dtype, 2, 24, 40, 8, 64, 3, 3, 1, with_q=1, what="wgrad", expect="wg5")
+    assert lab.backward_case("up2 3x3 128->64", dtype, 2, 12, 20, 128, 64, 3, 3, 1, mode=1, with_q=0, what="dgrad", expect="cvp")
+    assert lab.backward_case("up2 3x3 128->64 ragged", dtype, 1, 9, 7, 128, 64, 3, 3, 1, mode=1, with_q=0, what="dgrad", expect="cvp")
+    # (with the deferred correction on the incoming gradient this launch falls back to the generic kernel - the family assertion
+    # found that in its first run; the plan materialises that gradient, so the head never runs it that way - still right:)
+    assert lab.backward_case("up2 3x3 128->64 q", dtype, 1, 9, 7, 128, 64, 3, 3, 1, mode=1, with_q=1, what="dgrad", expect="generic")
 
 
 # ------------------------------------------------------------------------------------------------ (2) the timed networks, fp16
@@ -176,6 +200,10 @@ def test_c2_c3_networks_fp16_against_oracle_emulation(variant, H, W):
     assert e["loss"] < 5e-3, e
     assert e["logits"] < max(2e-2, 1.0 * e["y_logits"]), e      # the HIP path is closer to the emulation than the emulation to fp64
     assert e["grads"] < max(5e-2, 1.0 * e["y_grads"]), e
+    # per tensor (round 4): at this depth single tensors are noise-dominated on either side - measured worst 0.35 ... 0.55
+    # (a 1x1 or 3x3 weight of blocks 1 / 4, a different one per size) - so the bound only catches a tensor that is plainly wrong;
+    # the sharp per-tensor bounds are the two-block net's below
+    assert e["worst_conv"][0] < 0.8, e["worst_conv"]
 
 
 # ------------------------------------------------------------------------------------------------ (3) bf16 at layer depth
@@ -203,6 +231,7 @@ def test_two_block_net_layer_level_16bit(dtype, storage, tol_log, tol_g):
     print(f"two-block net {dtype}: logits {e['logits']:.3e} (emulation vs fp64 {e['y_logits']:.3e}), loss {e['loss']:.3e}, "
           f"grads rel L2 {e['grads']:.3e} (emulation vs fp64 {e['y_grads']:.3e}), worst conv tensor {e['worst_conv'][0]:.3e} {e['worst_conv'][1]}")
     assert e["logits"] < tol_log and e["loss"] < tol_log and e["grads"] < tol_g, e
+    assert e["worst_conv"][0] < {"fp16": 0.15, "bf16": 0.4}[dtype], e["worst_conv"]   # measured 0.070 / 0.199 (block 2's conv1.weight)
 
 
 # ------------------------------------------------------------------------------------------------ (4) the compact effective gradient
@@ -295,6 +324,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
     model = model.to(DEV).train()
     rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=3))
     grads, labels = {}, {}
+    monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")     # (held-back phase launches are not merged into one: compare like with like)
     for off in (0, 1):
         if off:
             monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
@@ -307,6 +337,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
         labels[off] = plan_labels(model._last[0])
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
+    monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
     model._plans.clear()
     assert sorted(labels[0]) == sorted(labels[1])
     first_head_w = {o: next(i for i, lab in enumerate(labels[o]) if lab.startswith(("wgp.", "wg5.")) and "/h." in lab) for o in (0, 1)}
@@ -314,3 +345,37 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
     assert first_head_w[0] > last_dec_dgrad[0] and first_head_w[1] < last_dec_dgrad[1], (first_head_w, last_dec_dgrad)
     for k in grads[0]:
         assert _rel(grads[0][k], grads[1][k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("bf16", 1e-3)])
+def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
+    """Round 4: the four output-parity phases of the head's 3x3 weight gradient (wgp.hip) run as ONE launch - phase p of a tile range
+    beside the other phases of that range on one XCD, so the half-resolution input is fetched from HBM once.  Same arithmetic per
+    phase: against four launches (DMM_NO_WGP_MERGE=1) the weight gradient agrees to the order of the fp32 atomics."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=3))    # 48 x 80 phase grid: 6 x 5 tiles, ragged in neither
+    grads, nl = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
+        model._plans.clear()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0])
+        nl[off] = sum(lab.startswith("wgp.") and lab.endswith("h.refine0") for lab in labels)
+        grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
+    model._plans.clear()
+    assert (nl[0], nl[1]) == (1, 4), nl
+    k = "dec_out_to_heat_maps.refine0.weight"
+    assert float(grads[1][k].abs().max()) > 0
+    assert _rel(grads[0][k], grads[1][k]) < tol, _rel(grads[0][k], grads[1][k])
+    for k2 in grads[0]:
+        assert _rel(grads[0][k2], grads[1][k2]) < 2e-3, k2

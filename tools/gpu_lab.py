@@ -33,7 +33,18 @@ def relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transposed=0, mode=0, bn=1, seed=0):
+def _check_family(res_name, expect):
+    """Did the family the case names really run?  (The single-kernel entry points fall back to the generic kernels silently.)"""
+    if expect is None:
+        return True
+    ran = _lib.impls_since_reset()
+    ok = expect in ran
+    if not ok:
+        print(f"FAIL {res_name}: expected kernel family {expect!r}, ran {sorted(ran)}", flush=True)
+    return ok
+
+
+def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transposed=0, mode=0, bn=1, seed=0, expect_wgrad=None):
     g = torch.Generator().manual_seed(seed)
     dt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[dtype]
     x = (torch.randn(B, Cin, H, W, generator=g) * 2 + 0.5)
@@ -79,9 +90,11 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
     # wgrad
     dyd = nhwc(dy, dt).to(DEV)
     dwd = torch.full(wshape, float("nan"), device=DEV)
+    _lib.impls_since_reset()
     _lib.check(L.dmm_conv_wgrad(C.byref(d), xd.data_ptr(), dyd.data_ptr(), sd.data_ptr(), hd.data_ptr(), dwd.data_ptr(),
                                 scratch.data_ptr(), st))
     torch.cuda.synchronize()
+    fam_ok = _check_family(name + " wgrad", expect_wgrad)
     res["wgrad"] = relerr(dwd.cpu(), wq.grad)
     # dgrad (BN fused)
     if bn and not (mode == 0 and not transposed and stride != 1):
@@ -100,7 +113,7 @@ def conv_case(name, dtype, mfma, B, H, W, Cin, Cout, R, S, stride, pad, transpos
     tol = {0: 2e-5, 1: 3e-3, 2: 2.5e-2}[dtype]   # relative to the tensor's max: fp32 / f16 (11 bits) / bf16 (8 bits) storage
     bad = [k for k, v in res.items() if not (v < tol)]
     print(f"{'FAIL' if bad else 'ok  '} {name:28s} dt={dtype} mfma={mfma} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
-    return not bad
+    return not bad and fam_ok
 
 
 def _eff_setup(g, dt, B, Cout, Ho, Wo, with_q):
@@ -119,7 +132,8 @@ def _eff_setup(g, dt, B, Cout, Ho, Wo, with_q):
     return dy, dyq, yf, q, r, eff
 
 
-def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with_q=1, acc=0, what="dgrad", seed=0, ref_dev="cpu"):
+def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with_q=1, acc=0, what="dgrad", seed=0, ref_dev="cpu", mode=0,
+                  expect=None):
     """The backward launches of the timed configuration, each through its C-ABI entry point against autograd of
     torch.nn.functional on the CPU (fp32 reference of the same op, 16-bit-rounded operands):
       what = "fused":  dmm_conv1x1_backward_fused (bw1.hip): data + weight gradient of a 1x1 bottleneck convolution
@@ -141,7 +155,12 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     z = xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     a = F.relu(z).requires_grad_(True)
     wq = w.clone().requires_grad_(True)
-    y = F.conv_transpose2d(a, wq, stride=2, padding=1, output_padding=1) if transposed else F.conv2d(a, wq, padding=pad)
+    if transposed:
+        y = F.conv_transpose2d(a, wq, stride=2, padding=1, output_padding=1)
+    elif mode == 1:   # the head's 3x3 over the nearest-x2 upsampled input (M:120, M:126)
+        y = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), wq, padding=pad)
+    else:
+        y = F.conv2d(a, wq, padding=pad)
     Ho, Wo = y.shape[2], y.shape[3]
     dy, dyq, yf, q, r, eff = _eff_setup(g, dt, B, Cout, Ho, Wo, with_q)
     (y * eff).sum().backward()
@@ -150,7 +169,7 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     gx_ref = dz * scale.view(1, -1, 1, 1) + (gold.float() if acc else 0.0)
     xhat = (xq.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
     d = _lib.ConvDesc(dtype=dtype, use_mfma=1, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, stride=2 if transposed else 1, pad=pad,
-                      transposed=transposed, mode=0, bn_relu=1)
+                      transposed=transposed, mode=mode, bn_relu=1)
     scratch = torch.zeros(L.dmm_conv_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
     xd, dyd = nhwc(x, dt).to(DEV), nhwc(dy, dt).to(DEV)
     yfd = nhwc(yf, dt).to(DEV) if with_q else None
@@ -162,6 +181,7 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     gxd = nhwc(gold.float(), dt).to(DEV) if acc else torch.full((B, H, W, Cin), float("nan"), dtype=dt, device=DEV)
     red = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
     dwd = torch.full(wshape, float("nan"), device=DEV)
+    _lib.impls_since_reset()
     if what == "fused":
         _lib.check(L.dmm_conv1x1_backward_fused(C.byref(d), xd.data_ptr(), dyd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(),
                                                 ptr(yfd), ptr(qd), ptr(rd), gxd.data_ptr(), acc, dwd.data_ptr(), red.data_ptr(),
@@ -173,6 +193,7 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
         _lib.check(L.dmm_conv_wgrad_ex(C.byref(d), xd.data_ptr(), dyd.data_ptr(), sd.data_ptr(), hd.data_ptr(), ptr(yfd), ptr(qd), ptr(rd),
                                        1 if what == "wgradT" else 0, dwd.data_ptr(), scratch.data_ptr(), st))
     torch.cuda.synchronize()
+    fam_ok = _check_family(f"{what} {name}", expect)
     if what in ("fused", "dgrad"):
         res["dgrad"] = relerr(nchw(gxd).cpu(), gx_ref.cpu())
         res["red1"] = relerr(red[:Cin].cpu(), dz.double().sum(dim=(0, 2, 3)).cpu())
@@ -182,10 +203,10 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     tol = {0: 2e-5, 1: 3e-3, 2: 2.5e-2}[dtype]
     bad = [k for k, v in res.items() if not (v < tol)]
     print(f"{'FAIL' if bad else 'ok  '} {what:6s} {name:28s} dt={dtype} q={with_q} acc={acc} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
-    return not bad
+    return not bad and fam_ok
 
 
-def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn, transposed=0, reps=3):
+def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn, transposed=0, reps=3, expect=None):
     """A forward convolution at a PRODUCTION size through the C ABI, several times on identical operands: against torch's GPU
     convolution (fp32 on the same 16-bit-rounded operands) and run to run (bitwise).  Timing-dependent hazards of the LDS pipelines
     (a refill landing before a queued fragment read has executed) only show with the chip full; parity-test shapes cannot see them."""
@@ -205,6 +226,7 @@ def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn,
     scratch = torch.zeros(L.dmm_conv_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dt)
     outs = []
+    _lib.impls_since_reset()
     for _ in range(reps):
         yd = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), dtype=dt, device=DEV)
         stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
@@ -217,7 +239,7 @@ def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn,
     errs = [float((o - ref).abs().max()) / top for o in outs]
     nbad = [int(((o - ref).abs() > tol * top).sum()) for o in outs]
     ndiff = [int((o != outs[0]).sum()) for o in outs[1:]]
-    ok = max(errs) < tol and not any(ndiff)
+    ok = max(errs) < tol and not any(ndiff) and _check_family("production " + name, expect)
     print(f"{'ok  ' if ok else 'FAIL'} production {name:36s} dt={dtype} err " + " ".join(f"{e:.2e}" for e in errs) + f" bad {nbad} run-to-run differing {ndiff}", flush=True)
     return ok
 
