@@ -109,6 +109,15 @@ struct ConvArgs {
   // red1 / red2 are null in that pass: the reductions were the first pass, which stored nothing).
   const float* eq;
   const float* er;
+  // conv3.hip, forward: several output-parity phases of ONE convolution in one launch (nphase = 0: one phase, the fields above).
+  // The phases share both gathered operands and the output tensor and differ in their taps, packed weights and output parity; the
+  // four phases of a tile are neighbours in the tile order, i.e. they run at the same time on one XCD and the half-resolution
+  // input is fetched from HBM once (four launches swept it four times).
+  int nphase;
+  const void* ph_wpack[4];
+  short ph_taps0[4][4];    // taps of seg[0] per phase
+  short ph_taps1[4][9];    // taps of seg[1] per phase
+  signed char ph_py[4], ph_px[4];
 };
 
 // Weight-gradient GEMM:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k], same A gather as the forward conv.

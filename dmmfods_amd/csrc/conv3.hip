@@ -45,6 +45,7 @@ struct Conv3Args {
   int tiles_y, tiles_x, ntiles;
   int dymin0, dxmin0;  // smallest tap offsets of segment 0 (its halo starts there)
   int dymin1, dxmin1;  // ... of the raw-input segment (stride-2 source)
+  signed char ph_dymin0[4], ph_dxmin0[4], ph_dymin1[4], ph_dxmin1[4];  // ... per phase of a multi-phase launch (ConvArgs::nphase)
 };
 
 // CS = 16-byte channel slots per pixel of the wide segment (C = 8 CS, a multiple of 32; 0: no wide segment); SPAN = its tap
@@ -110,10 +111,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   // round, so a workgroup stays on "its" XCD's contiguous range of the tile order): the halo loads of the NEXT tile are issued right
   // behind the last MFMA of the current one and fly under its epilogue (round 3 ablation: load wait, K loop and epilogue of a tile
   // simply added up - 0.5 + 0.85 + 0.6 ms on the head's forward phases - overlapped only across the 2-3 workgroups of a CU).
+  // Multi-phase launches (forward, the head's 3x3 over the upsampled map): the walk is over (tile, phase) pairs, phase fastest, so
+  // the four phases of a tile are neighbours in the XCD's range - four workgroups of one XCD work on them at the same time and the
+  // halo comes from HBM once.
+  constexpr bool MULTI = EPI == EPI_STORE && SEG0 && SEG1;
+  const int nph = (MULTI && a.nphase > 0) ? a.nphase : 1;
+  const int nitems = g.ntiles * nph;
   int lt = blockIdx.x;
-  int b, y0, x0;
+  int b, y0, x0, ph = 0;
+  int dymin0 = g.dymin0, dxmin0 = g.dxmin0, dymin1 = g.dymin1, dxmin1 = g.dxmin1;
   auto decode = [&](int l) {
-    int tile = xcd_remap(l, g.ntiles);
+    int tile = xcd_remap(l, nitems);
+    if constexpr (MULTI) {
+      if (nph > 1) {
+        ph = tile % nph; tile /= nph;
+        dymin0 = g.ph_dymin0[ph]; dxmin0 = g.ph_dxmin0[ph]; dymin1 = g.ph_dymin1[ph]; dxmin1 = g.ph_dxmin1[ph];
+      }
+    }
     const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
     const int ty_i = tile % g.tiles_y;
     b = tile / g.tiles_y;
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   // ---- the first two weight groups start streaming now ----
   // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain it (vmcnt(0)) in front of the next ds_read
   // as it does for the builtin (it cannot prove that the LDS ranges differ); the waits are the counted ones in the K loop.
-  const T* wp = (const T*)a.wpack;
+  const T* wp = (const T*)a.wpack;   // (per phase in a multi-phase launch: set at the top of the tile loop)
   int woff[NPW];   // per-lane source offset (elements) inside a group's block (the group's chunks are contiguous: Npad == BN)
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     for (int i = 0; i < NI; ++i) {
       const int hp = hp0 + PSTEP * i;
       const int hy = hp / HW, hx = hp - hy * HW;
-      const int sy = y0 + g.dymin0 + hy, sx = x0 + g.dxmin0 + hx;
+      const int sy = y0 + dymin0 + hy, sx = x0 + dxmin0 + hx;
       ok[i] = hp < HH * HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws;
       // branch-free: a slot outside the picture loads a clamped (valid) address and is zeroed when the image is written; a
       // conditional load would make the compiler wait for each load before the next branch
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       for (int i = 0; i < NI1; ++i) {
         const int hp = tid + NTHREADS * i;
         const int hy = hp / SM::HW1, hx = hp - hy * SM::HW1;
-        const int sy = TSTR * y0 + g.dymin1 + hy, sx = TSTR * x0 + g.dxmin1 + hx;
+        const int sy = TSTR * y0 + dymin1 + hy, sx = TSTR * x0 + dxmin1 + hx;
         okb[i] = hp < NSL1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws;
         const int cy = min(max(sy, 0), sg1.Hs - 1), cx = min(max(sx, 0), sg1.Ws - 1);
         const size_t pix = (C3_DBG & 1) ? 0 : (size_t)(b * sg1.Hs + cy) * sg1.Ws + cx;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
   // this lane's pixel: tile row 2*wave + (r >> 4), column r & 15
   const int ty = 2 * wave + (r >> 4), tx = r & 15;
-  const int abase = (ty - g.dymin0) * RP + (tx - g.dxmin0) * PP + h * 16;
+  int abase = (ty - g.dymin0) * RP + (tx - g.dxmin0) * PP + h * 16;
   const int bsw = (r >> 2) & 3;
   // tap offsets: scalar loads from the kernel arguments, all before the loop - no compiler-counted memory operation may sit
   // between the DMA issue and the counted wait, or hipcc's wait for it drains the DMA as well
@@ -229,12 +243,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       }
   }
 
+  int opy = a.py, opx = a.px;   // output parity of the item being computed
   while (true) {   // ---- one tile (b, y0, x0); its halo is in the registers ----
+  if constexpr (MULTI) {
+    if (nph > 1) {   // this item's phase: weights, tap offsets, output parity (scalar loads from the kernel arguments)
+      wp = (const T*)a.ph_wpack[ph];
+      opy = a.ph_py[ph]; opx = a.ph_px[ph];
+      abase = (ty - dymin0) * RP + (tx - dxmin0) * PP + h * 16;
+#pragma unroll
+      for (int tap = 0; tap < SM::NTAPS0; ++tap) {
+        const int tw = a.ph_taps0[ph][tap];
+        toffs[tap] = (int)(signed char)(tw & 0xff) * RP + (int)(signed char)((tw >> 8) & 0xff) * PP;
+      }
+      const int abase1 = (TSTR * ty - dymin1) * RP1 + (TSTR * tx - dxmin1) * 16;
+#pragma unroll
+      for (int c = 0; c < SM::NCH1; ++c)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int j0 = 4 * c + 2 * s2;
+          const int t0 = a.ph_taps1[ph][j0 < NT1 ? j0 : 0], t1 = a.ph_taps1[ph][j0 + 1 < NT1 ? j0 + 1 : 0];
+          const int o0 = (int)(signed char)(t0 & 0xff) * RP1 + (int)(signed char)((t0 >> 8) & 0xff) * 16;
+          const int o1 = (int)(signed char)(t1 & 0xff) * RP1 + (int)(signed char)((t1 >> 8) & 0xff) * 16;
+          off1[2 * c + s2] = (j0 + h < NT1) ? abase1 + (h ? o1 : o0) : -1;
+        }
+    }
+  }
   issue_w(0);      // the first two weight groups start streaming now (the ring is free: the previous tile's staging has been read)
   if (NGRP > 1) issue_w(1);
   if (tid < BM) {
     const int y = y0 + tid / C3_TW, x = x0 + tid % C3_TW;
-    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + opy) * a.Wout + x * a.ostride + opx : -1;
   }
   if (tid < 2 * BN) red[tid] = 0.0;
 
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   // the next halo as well costs them a workgroup per CU - measured 1.87 -> 2.6 ms on the dense 3x3 data gradients)
   constexpr bool PERSIST = EPI == EPI_STORE;
   const int lnext = lt + gridDim.x;
-  const bool more = PERSIST && lnext < g.ntiles;   // (workgroup-uniform)
+  const bool more = PERSIST && lnext < nitems;   // (workgroup-uniform)
   if (more) { decode(lnext); load_halo(); }
   if (!((C3_DBG & 8) && acc[0][0] != 123.f)) {
   // reuse the images for staging
@@ -476,7 +514,7 @@ static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   static const int rounds = getenv("DMM_C3_ROUNDS") ? atoi(getenv("DMM_C3_ROUNDS")) : 1;
   const int per_cu = std::min(4, (160 * 1024) / SM::bytes);
-  int nwg = g.ntiles;
+  int nwg = g.ntiles * (g.c.nphase > 0 ? g.c.nphase : 1);
   if (EPI == EPI_STORE && rounds > 0 && nwg > per_cu * cus * rounds) nwg = per_cu * cus * rounds / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), SM::bytes, st, g);
   return hipGetLastError();
@@ -550,6 +588,20 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
     if (a.nseg == 2) {
       tstr = 2;
       if (!thin_ok(a.seg[1], 2) || tspan != 2 || (a.seg[1].scale != nullptr) != (sg.scale != nullptr)) return hipErrorNotSupported;
+    }
+  }
+  if (a.nphase < 0 || a.nphase > 4) return hipErrorNotSupported;
+  if (a.nphase > 0) {  // several output-parity phases in one launch: the forward of the two-segment head convolution only
+    if (epi != EPI_STORE || a.nseg != 2 || sg.ntaps != 4 || a.seg[1].ntaps != 9) return hipErrorNotSupported;
+    for (int ph = 0; ph < a.nphase; ++ph) {
+      Seg t0 = sg, t1 = a.seg[1];
+      for (int t = 0; t < 4; ++t) t0.taps[t] = a.ph_taps0[ph][t];
+      for (int t = 0; t < 9; ++t) t1.taps[t] = a.ph_taps1[ph][t];
+      int y0, x0, y1, x1, sp0, sp1;
+      if (!tap_box(t0, y0, x0, sp0) || sp0 != span || !tap_box(t1, y1, x1, sp1) || sp1 != tspan || a.ph_wpack[ph] == nullptr ||
+          a.ph_py[ph] < 0 || a.ph_py[ph] >= a.ostride || a.ph_px[ph] < 0 || a.ph_px[ph] >= a.ostride)
+        return hipErrorNotSupported;
+      g.ph_dymin0[ph] = (signed char)y0; g.ph_dxmin0[ph] = (signed char)x0; g.ph_dymin1[ph] = (signed char)y1; g.ph_dxmin1[ph] = (signed char)x1;
     }
   }
   if (a.nseg == 1 && (a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo)) return hipErrorNotSupported;

@@ -582,6 +582,34 @@ struct Builder {
         if (training) P.logits_op_train = (int)ops->size() - 1; else P.logits_op_eval = (int)ops->size() - 1;
       }
     }
+    // Four phases of the two-segment head convolution, all on conv3.hip: ONE launch that walks (tile, phase) pairs - the four phases of
+    // a tile run side by side on one XCD and the half-resolution input (0.8 GB at C2) comes from HBM once instead of four times.
+    if (c.phases.size() == 4 && c.nseg == 2 && ops->size() >= 4 && getenv("DMM_NO_C3_MERGE") == nullptr) {
+      const size_t first = ops->size() - 4;
+      bool ok = true;
+      for (size_t k = first; k < ops->size(); ++k) {
+        const Op& po = (*ops)[k];
+        ok = ok && po.kind == OP_IGEMM && po.epi == EPI_STORE && po.impl == IMPL_CONV3 && po.c.nseg == 2 && po.c.seg[0].ntaps == 4 &&
+             po.c.seg[1].ntaps == 9 && po.leaf == (*ops)[first].leaf;
+      }
+      if (ok) {
+        Op merged = (*ops)[first];
+        merged.c.nphase = 4;
+        merged.flops = 0; merged.bytes = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+          const Op& po = (*ops)[first + ph];
+          for (int t = 0; t < 4; ++t) merged.c.ph_taps0[ph][t] = po.c.seg[0].taps[t];
+          for (int t = 0; t < 9; ++t) merged.c.ph_taps1[ph][t] = po.c.seg[1].taps[t];
+          merged.c.ph_wpack[ph] = po.c.wpack;
+          merged.c.ph_py[ph] = (signed char)po.c.py; merged.c.ph_px[ph] = (signed char)po.c.px;
+          merged.flops += po.flops; merged.bytes += po.bytes;
+        }
+        if (igemm_pick(merged.c, dtype, EPI_STORE, d.use_mfma != 0) == IMPL_CONV3) {
+          ops->resize(first);
+          ops->push_back(merged);
+        }
+      }
+    }
   }
 
   void fill_grad_seg(Seg& s, int buf, int ch0, int C, const std::vector<Tap>& taps, int istride) {

@@ -379,3 +379,33 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
     assert _rel(grads[0][k], grads[1][k]) < tol, _rel(grads[0][k], grads[1][k])
     for k2 in grads[0]:
         assert _rel(grads[0][k2], grads[1][k2]) < 2e-3, k2
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_head_forward_phases_in_one_launch(dtype, monkeypatch):
+    """Round 4: the four output-parity phases of the head's first convolution (conv3.hip: 2x2 merged taps over the half-resolution
+    decoder output + 3x3 stride-2 taps over the raw input) run as ONE launch that walks (tile, phase) pairs.  Same arithmetic per
+    phase, no float atomics on stored values: against four launches (DMM_NO_C3_MERGE=1) the logits must be EQUAL bit for bit."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=11))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=3))
+    outs, nl = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_C3_MERGE", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_C3_MERGE", raising=False)
+        model._plans.clear()
+        with torch.no_grad():
+            outs[off] = model(rgb, lidar).clone()
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0])
+        nl[off] = sum(lab.startswith("conv3.store") and lab.endswith("h.refine0") for lab in labels)
+    monkeypatch.delenv("DMM_NO_C3_MERGE", raising=False)
+    model._plans.clear()
+    assert (nl[0], nl[1]) == (1, 4), nl
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
