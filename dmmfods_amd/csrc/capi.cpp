@@ -171,27 +171,9 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       // DMM_SIDE_PRIO = hi | mid: experiment knob (default: lowest priority, the data-gradient chain is the longer dependency chain)
       const char* sp = getenv("DMM_SIDE_PRIO");
       const int prio = sp && sp[0] == 'h' ? hi : (sp && sp[0] == 'm' ? (lo + hi) / 2 : lo);
-      // DMM_SIDE_CUS=<n>[:<pattern>]: experiment (round 4) - confine the side stream to n of the 256 compute units (pattern "s": every
-      // (256/n)-th unit, i.e. the same share of every XCD if units are numbered round-robin; "f": the first n; "x": n/8 consecutive
-      // units of each block of 32), so that its memory-bound kernels stop inflating the main chain's (a CU-masked stream has no priority)
-      const char* cm = getenv("DMM_SIDE_CUS");
-      hipError_t se;
-      if (cm && atoi(cm) > 0 && atoi(cm) < 256) {
-        const int ncu = atoi(cm);
-        const char* col = strchr(cm, ':');
-        const char pat = col ? col[1] : 's';
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < ncu; ++k) {
-          int bit;
-          if (pat == 'f') bit = k;
-          else if (pat == 'x') bit = (k % 8) * 32 + k / 8;
-          else bit = k * (256 / ncu);
-          mask[bit >> 5] |= 1u << (bit & 31);
-        }
-        se = hipExtStreamCreateWithCUMask(&s2, 8, mask);
-      } else {
-        se = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio);
-      }
+      // (round 4: confining this stream to 32-128 CUs with hipExtStreamCreateWithCUMask made the step 41-57 ms instead of 28 - even the
+      // one-stream profiling pass slowed down; profiles/r04/ablations.txt)
+      const hipError_t se = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio);
       if (se != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
       hipEvent_t je;
       if (hipEventCreateWithFlags(&je, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
@@ -235,13 +217,6 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     }
     const bool sel = selected(o);
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i)], lst);
-    // timing experiment only (WRONG gradients): DMM_SKIP_WGRAD=h skips the head's / decoder's weight-gradient launches, =e the
-    // encoder's, =a all - how much of the step is the side stream's work, and would deferring a part of it pay?
-    static const char* skipw = getenv("DMM_SKIP_WGRAD");
-    if (skipw && (o.kind == OP_WGRAD || o.kind == OP_BW1RED)) {
-      const bool late = strstr(o.label, "/h.") != nullptr || strstr(o.label, "/d.") != nullptr;
-      if (skipw[0] == 'a' || (skipw[0] == 'h' && late) || (skipw[0] == 'e' && !late)) continue;
-    }
     switch (o.kind) {
       case OP_MEMSET: e = hipMemsetAsync(o.ms.p, 0, o.ms.bytes, lst); break;
       case OP_COPY: e = hipMemcpyAsync(o.cp.dst, o.cp.src, o.cp.bytes, hipMemcpyDeviceToDevice, lst); break;
