@@ -22,6 +22,8 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o
 python3 tools/pmc_traffic.py /tmp/pmcF /tmp/pmcW $out/pmc_hbm_traffic.json > $out/pmc_hbm_traffic.txt || exit 5
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d /tmp/pmcS -o run -- $B > $out/pmcS.log 2>&1 || exit 6
 python3 tools/pmc_sq.py /tmp/pmcS $out/pmc_sq_summary.csv || exit 7
+timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d /tmp/pmcL -o run -- $B > $out/pmcL.log 2>&1 || exit 7
+python3 tools/pmc_lds.py /tmp/pmcL > $out/pmc_lds_bank_conflicts.txt || exit 7
 for cfg in c1 c3 c4 c5; do
   timeout -k 10 240 python3 bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --table > $out/bench_$cfg.json 2> $out/bench_${cfg}_classes.txt || exit 8
 done
