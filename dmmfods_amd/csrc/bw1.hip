@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gather.h"
@@ -30,6 +31,10 @@ namespace dmm {
 #endif
 #ifndef B1_RAW_BAR
 #define B1_RAW_BAR 0        // experiment: raw s_barrier behind an LDS-only wait for the three barriers behind the prefetch
+#endif
+#ifndef B1_NT
+#define B1_NT 0  // experiment: 1 x / old gradient loads non-temporal, 2 the gradient store non-temporal (3 both): streamed once, they
+                 // should not evict the G / y tiles that the sibling workgroups of a row range share through the XCD's L2
 #endif
 #ifndef B1_GOLD_EARLY
 #define B1_GOLD_EARLY 0  // 1: request the old gradient in front of the MFMAs (round 2; 16 more live registers across both GEMMs)
@@ -67,6 +72,7 @@ __device__ __forceinline__ typename TT<T>::vec b1_frag(const b1_u32x2& lo, const
 template <typename T, int PQ, bool ACC_, bool PART>
 __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   constexpr bool ACC = ACC_ && !(B1_DBG & 32);
+  constexpr bool UNC = std::is_same<T, f16>::value;  // the second per-channel sum is taken uncentred and centred once per workgroup (f16 epilogue)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
   constexpr int SLOT = 8;
@@ -144,7 +150,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
       const int m = tile * B1_TM + p0 + 16 * i;
       if (m < a.M) okp |= 1u << i;
       const unsigned mm = (B1_DBG & 16) ? 0u : (unsigned)min(m, a.M - 1);
-      rx[i] = *(const V*)(xbase + (size_t)(mm * xpitch + xcol));
+      if (B1_NT & 1) rx[i] = __builtin_nontemporal_load((const V*)(xbase + (size_t)(mm * xpitch + xcol)));
+      else rx[i] = *(const V*)(xbase + (size_t)(mm * xpitch + xcol));
       rg[i] = *(const V*)(gbase + (size_t)(mm * gpitch + gcol));
       if constexpr (PQ == 2) ry[i] = *(const V*)(ybase + (size_t)(mm * ypitch + gcol));
     }
@@ -179,9 +186,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   issue(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
     // ---- operands to LDS (prologues once per element); raw x and the old gradient stay in registers for the epilogue ----
+    // FULL: all 64 rows of the tile exist (every tile but possibly the launch's last) - the row-validity selects in front of the LDS
+    // writes and the per-row branches of the epilogue are compiled out (a sixth of the loop's vector instructions, and the kernel is
+    // bound by them: 32 MFMA = 1024 cycles against ~500 VALU = 2000 cycles per wave and tile).  Only these two stretches exist twice;
+    // the GEMMs between them are shared, so the accumulators' live ranges are those of a single path.
     V xraw[NL], gold[ACC ? NL : 1];
-    const unsigned ok = okp;
-    {
+    const bool full = (tile + 1) * B1_TM <= a.M;   // (workgroup-uniform)
+    const unsigned okt = okp;
+    auto stage = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
       V z;
 #pragma unroll
       for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
@@ -191,8 +204,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
           xraw[i] = rx[i];
-          const bool v = ((ok >> i) & 1) != 0;
-          *(V*)(Ai + lds0 + 4096 * i) = (v && cvalid) ? bn_relu_slot(rx[i], kx) : z;
+          const bool v = FULL || ((okt >> i) & 1) != 0;
+          // (channels past C_in: their scale / shift constants are zeros, relu(0 x + 0) = 0 needs no select)
+          const V av_ = bn_relu_slot(rx[i], kx);
+          *(V*)(Ai + lds0 + 4096 * i) = v ? av_ : z;
         }
       }
       {
@@ -201,13 +216,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
         if (PQ == 2) { kg.k0 = load_fv<SLOT>(kc + 4 * B1_CT + cs * SLOT); kg.k1 = load_fv<SLOT>(kc + 5 * B1_CT + cs * SLOT); }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-          const bool v = ((ok >> i) & 1) != 0;
+          const bool v = FULL || ((okt >> i) & 1) != 0;
           V gv = rg[i];
           if constexpr (PQ == 2) gv = eff_grad_slot(rg[i], ry[i], kg);
           *(V*)(Gi + lds0 + 4096 * i) = v ? gv : z;
         }
       }
-    }
+    };
+    if (UNC && full) stage(std::true_type()); else stage(std::false_type());   // (bf16: the second copy spills its generic epilogue)
     __syncthreads();  // images (and, the first time, the weight slice) complete
 #if !B1_LATE_PREFETCH
     if (tile + 1 < t_end) issue(tile + 1);
@@ -258,7 +274,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const unsigned mm = (unsigned)min(tile * B1_TM + p0 + 16 * i, a.M - 1);
-        gold[i] = *(const V*)(obase + (size_t)(mm * opitch + xcol));
+        if (B1_NT & 1) gold[i] = __builtin_nontemporal_load((const V*)(obase + (size_t)(mm * opitch + xcol)));
+        else gold[i] = *(const V*)(obase + (size_t)(mm * opitch + xcol));
       }
     }
 #endif
@@ -301,33 +318,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
     float s1[SLOT], s2[SLOT];
 #pragma unroll
     for (int e = 0; e < SLOT; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    if (cvalid) {
-      float sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+    auto finish = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      float sc[SLOT], sh[SLOT], mu[UNC ? 1 : SLOT], is[UNC ? 1 : SLOT];
       load_f32s<SLOT>(kc + cs * SLOT, sc); load_f32s<SLOT>(kc + B1_CT + cs * SLOT, sh);
-      load_f32s<SLOT>(kc + 2 * B1_CT + cs * SLOT, mu); load_f32s<SLOT>(kc + 3 * B1_CT + cs * SLOT, is);
+      if constexpr (!UNC) { load_f32s<SLOT>(kc + 2 * B1_CT + cs * SLOT, mu); load_f32s<SLOT>(kc + 3 * B1_CT + cs * SLOT, is); }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        if (!((ok >> i) & 1)) continue;
+        if (!FULL && !((okt >> i) & 1)) continue;
         const int p = p0 + 16 * i;
-        float av[SLOT], xf[SLOT], gf[SLOT];
+        float av[SLOT];
 #pragma unroll
         for (int e = 0; e < SLOT; e += 4) {
           const f32x4 t4 = *(const f32x4*)(Cs + p * B1_CT + ((cs * SLOT + e) ^ (((p >> 2) & 1) << 5)));
           av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
         }
-        vec_to_f32<T>(xraw[i], xf);
-        if constexpr (ACC) vec_to_f32<T>(gold[i], gf);
-#pragma unroll
-        for (int e = 0; e < SLOT; ++e) {
-          const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
-          s1[e] += dz;
-          s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
-          gf[e] = (ACC ? gf[e] : 0.f) + sc[e] * dz;
-        }
         const unsigned m = (unsigned)(tile * B1_TM + p);
-        if (!(B1_DBG & 64) || gf[0] == 1.2345e33f) *(V*)(obase + (size_t)(m * opitch + xcol)) = f32_to_vec<T>(gf);
+        if constexpr (UNC) {  // f16: mixed-precision instructions on the packed halves, uncentred second sum (gather.h bnbwd_slot)
+          const V ov = bnbwd_slot<ACC>(av, xraw[i], gold[ACC ? i : 0], sc, sh, s1, s2);
+          if (B1_NT & 2) __builtin_nontemporal_store(ov, (V*)(obase + (size_t)(m * opitch + xcol)));
+          else if (!(B1_DBG & 64) || av[0] == 1.2345e33f) *(V*)(obase + (size_t)(m * opitch + xcol)) = ov;
+        } else {
+          float xf[SLOT], gf[SLOT];
+          vec_to_f32<T>(xraw[i], xf);
+          if constexpr (ACC) vec_to_f32<T>(gold[i], gf);
+#pragma unroll
+          for (int e = 0; e < SLOT; ++e) {
+            const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+            s1[e] += dz;
+            s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+            gf[e] = (ACC ? gf[e] : 0.f) + sc[e] * dz;
+          }
+          if (!(B1_DBG & 64) || gf[0] == 1.2345e33f) *(V*)(obase + (size_t)(m * opitch + xcol)) = f32_to_vec<T>(gf);
+        }
       }
-    }
+    };
+    if (cvalid) { if (UNC && full) finish(std::true_type()); else finish(std::false_type()); }
     // per-tile partials cover 4 rows per thread: fold the 4 lanes of a wave that share the slot column (lane swaps: every lane ends
     // up with 4 of the 16 finished wave totals), then fp64 in LDS - 4 LDS atomics per lane instead of 16 on a quarter of the lanes
     fold_to_lds<16, SLOT, B1_CT>(s1, s2, red, cs, cvalid, lane);
@@ -342,8 +368,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   // ---- results of the walk: per-channel sums (one fp64 atomic per channel and workgroup), the weight-gradient slice ----
   if (tid < B1_CT && c0 + tid < a.N) {
     const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-    atomic_add_f64(a.red1 + rep + c0 + tid, red[fold_slot<16, SLOT>(0, tid)]);
-    atomic_add_f64(a.red2 + rep + c0 + tid, red[fold_slot<16, SLOT>(1, tid)]);
+    const double S1 = red[fold_slot<16, SLOT>(0, tid)];
+    double S2 = red[fold_slot<16, SLOT>(1, tid)];
+    if constexpr (UNC) S2 = (S2 - (double)kc[2 * B1_CT + tid] * S1) * (double)kc[3 * B1_CT + tid];  // sum dz x -> sum dz xhat
+    atomic_add_f64(a.red1 + rep + c0 + tid, S1);
+    atomic_add_f64(a.red2 + rep + c0 + tid, S2);
   }
   const int c = c0 + 32 * wave + r;
   if constexpr (PART) {  // this workgroup's slot, in the layout of the dpack slice (whole slot: the reduction reads all of it)

@@ -164,7 +164,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   size_t nfork = 0;
   bool forked = false;
   if (overlap) {
-    while ((int)p->side_streams.size() < nside) {
+    while ((int)p->side_streams.size() < nside + 1) {  // [nside]: the pack stream
       int lo = 0, hi = 0;
       hipDeviceGetStreamPriorityRange(&lo, &hi);
       hipStream_t s2;
@@ -181,7 +181,16 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       p->join_events.push_back((void*)je);
     }
   }
-  auto join = [&]() {
+  // The pack stream (side_streams[1]): the launch that packs the weights of the LATE layers (leaf == 2) runs there beside the first
+  // layers of the forward pass; OP_JOIN with epi == 1 in front of the first late layer makes the main stream wait for it.
+  bool pack_pending = false;
+  auto join_pack = [&]() {
+    if (pack_pending) {
+      hipStreamWaitEvent(st, (hipEvent_t)p->join_events[nside], 0);
+      pack_pending = false;
+    }
+  };
+  auto join_side = [&]() {
     if (forked) {
       for (int k = 0; k < nside; ++k) {
         hipEventRecord((hipEvent_t)p->join_events[k], (hipStream_t)p->side_streams[k]);
@@ -190,6 +199,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       forked = false;
     }
   };
+  auto join = [&]() { join_side(); join_pack(); };
   // DMM_HOST_PROF=1: host time of the enqueue calls by op kind, printed when a list has run 20 times (tools/host_bound.py)
   static const bool host_prof = getenv("DMM_HOST_PROF") != nullptr;
   static double hp_launch[32] = {0}, hp_fork[32] = {0};
@@ -202,17 +212,22 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     double hp_t1 = hp_t0;
     // side-stream launches: weight gradients and the leaves of the backward graph (stem, raw-input branches)
     hipStream_t lst = st;
-    if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
+    if (overlap && o.leaf == 3) {
+      // a launch that continues a chain on the side stream (the second stream's encoder): everything it reads was produced by the
+      // launch in front of it on that stream, or before the chain's first launch (which forked from the main stream)
+      lst = (hipStream_t)p->side_streams[0];
+      forked = true;
+    } else if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
       if (nfork >= p->fork_events.size()) {
         hipEvent_t fe;
         if (hipEventCreateWithFlags(&fe, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
         p->fork_events.push_back((void*)fe);
       }
-      lst = (hipStream_t)p->side_streams[0];
+      lst = (hipStream_t)p->side_streams[o.leaf == 2 ? nside : 0];
       hipEvent_t fe = (hipEvent_t)p->fork_events[nfork++];
       hipEventRecord(fe, st);
       hipStreamWaitEvent(lst, fe, 0);
-      forked = true;
+      if (o.leaf == 2) pack_pending = true; else forked = true;
       if (host_prof) hp_t1 = now();
     }
     const bool sel = selected(o);
@@ -225,7 +240,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst, o.impl); break;
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
       case OP_BW1RED: e = launch_bw1_reduce(o.b1, lst); break;
-      case OP_JOIN: join(); break;  // the main stream waits for what the side stream has been given so far
+      case OP_JOIN: if (o.epi == 1) join_pack(); else join_side(); break;  // the main stream waits for what the side (epi 1: pack) stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
       case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, lst); break;
@@ -240,6 +255,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     if (e != hipSuccess) join();  // leave the main stream ordered after whatever the side stream already got
     if (e != hipSuccess) return fail(DMM_ERR_HIP, "op " + std::to_string(i) + " kind " + std::to_string(o.kind) + ": " + hipGetErrorString(e));
     if (sel) hipEventRecord((hipEvent_t)(*evs)[2 * (ev_offset + i) + 1], lst);
+    if (pack_pending && o.leaf == 2) hipEventRecord((hipEvent_t)p->join_events[nside], lst);
     if (o.signal >= 0 && !capturing) {  // a gradient bucket is final on this stream from here on
       while ((int)p->bucket_events.size() <= o.signal) {
         hipEvent_t be;

@@ -376,6 +376,41 @@ __device__ __forceinline__ f32x4 eff_grad_slot(const f32x4& g, const f32x4& x, c
   return o;
 }
 
+// BatchNorm + ReLU backward on one 16-byte slot of f16 (the epilogue of the fused data-gradient kernels): dy = the data gradient of
+// relu(bn(x)) (fp32, from the accumulators), x = the raw input of the norm, gold = the gradient already stored for x (ACC).
+//   dz = dy where fma(x, sc, sh) > 0 (the forward's own arithmetic), else 0;   s1 += dz;   s2 += dz * x  (UNCENTRED: the caller turns
+//   the finished fp64 total into the centred sum  (S2 - mean S1) * invstd  once per channel);   returns f16(gold + sc * dz).
+// The mixed-precision fmas read the f16 halves in place and round the result to f16 themselves: 6 instructions per element (mask 3,
+// sums 2, result 1) where the generic form (convert x, convert gold, centre, scale, convert back) needs 10-11.
+template <bool ACC>
+__device__ __forceinline__ f16x8 bnbwd_slot(const float (&dy)[8], const f16x8& x, const f16x8& gold, const float (&sc)[8],
+                                            const float (&sh)[8], float (&s1)[8], float (&s2)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xi = __builtin_bit_cast(u32x4, x), gi = __builtin_bit_cast(u32x4, gold);
+  u32x4 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float t0, t1;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(xi[p]), "v"(sc[2 * p]), "v"(sh[2 * p]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(xi[p]), "v"(sc[2 * p + 1]), "v"(sh[2 * p + 1]));
+    const float d0 = t0 > 0.f ? dy[2 * p] : 0.f, d1 = t1 > 0.f ? dy[2 * p + 1] : 0.f;
+    s1[2 * p] += d0;
+    s1[2 * p + 1] += d1;
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(s2[2 * p]) : "v"(xi[p]), "v"(d0));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s2[2 * p + 1]) : "v"(xi[p]), "v"(d1));
+    unsigned d;
+    if constexpr (ACC) {
+      asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(sc[2 * p]), "v"(d0), "v"(gi[p]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(sc[2 * p + 1]), "v"(d1), "v"(gi[p]));
+    } else {
+      asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(sc[2 * p]), "v"(d0));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(sc[2 * p + 1]), "v"(d1));
+    }
+    o[p] = d;
+  }
+  return __builtin_bit_cast(f16x8, o);
+}
+
 // narr: 0 = no prologue, 2 = BN+ReLU, 4 = effective gradient (run-time value used by PRO < 0 only)
 template <typename T, int PRO>
 __device__ __forceinline__ typename TT<T>::vec finish_slot(int narr, const RawSlot<T>& r, const SlotK<TT<T>::SLOT>& k) {

@@ -1243,17 +1243,17 @@ struct Builder {
   }
 
   void emit_pack_op(int kind) {
-    if (pack_split > 0) {  // the first convolution's weights, on the launch stream
+    if (pack_split > 0) {  // the early layers' weights, on the launch stream
       Op& o = push(kind);
       o.pk.descs = pack_dev;
       o.pk.prefix = prefix_dev;
       o.pk.ndesc = pack_split;
       o.pk.total_rows = pack_rows0;
       o.pk.grad_scale = 1.0f / d.loss_scale;
-      tag(o, "pack", "stem", 0, 0);
+      tag(o, "pack", "early", 0, 0);
     }
     Op& o = push(kind);
-    if (pack_split > 0) o.leaf = 1;  // side stream; OP_JOIN in front of the second convolution (emit_pack_join)
+    if (pack_split > 0) o.leaf = 2;  // pack stream; OP_JOIN (epi 1) in front of record pack_cut_rec (emit_forward_records)
     o.pk.descs = pack_dev + pack_split;
     o.pk.prefix = prefix_dev + pack_split;
     o.pk.ndesc = (int)P.packs.size() - pack_split;
@@ -1264,24 +1264,41 @@ struct Builder {
   // Mid fusion: the second stream's encoder (records [0, s2_recs)) shares nothing with the first stream's until the concat module
   // (record concat_rec) reads both.  Its forward launches go to the side stream beside the first stream's: each chain alone leaves
   // the chip idle between its dependent launches (finalize steps, small late-block grids).
+  // Round 4: the two encoders' records are emitted ALTERNATELY and the second stream's launches continue one chain on the side stream
+  // (leaf 3: no fork event per launch).  Emitted one encoder after the other, the host fed ~1 ms of side-stream launches before the
+  // first stream's first launch reached the queue; together with the join behind the full weight pack the main queue sat idle for
+  // 2.2 ms at the start of every C3/C4/C5 step (tools/probes/dump_first.py; profiles/r04/ablations.txt section 8).
   size_t s2_recs = 0, concat_rec = 0;
   const bool s2_overlap = getenv("DMM_NO_S2_OVERLAP") == nullptr;  // A/B knob
-  void emit_forward_records() {
-    for (size_t ri = 0; ri < recs.size(); ++ri) {
-      const Rec& r = recs[ri];
-      const bool beside = g.fusion == 2 && s2_overlap && s2_recs > 0;
-      if (beside && ri == concat_rec) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
-      // (record 0 - the second stream's stem, whose weights are the "stem" pack - stays on the launch stream: as a leaf it queued
-      // on the side stream BEHIND the pack of all other weights, and the join behind it then made the first stream's stem wait for
-      // both; now it runs beside that pack, which is what the pack split is for)
-      leaf_scope = beside && ri < s2_recs && (ri > 0 || pack_split == 0);
-      if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
-      leaf_scope = false;
-      if (ri == 0) emit_pack_join();
-    }
+  const bool s2_interleave = getenv("DMM_NO_S2_INTERLEAVE") == nullptr;  // A/B knob
+  void emit_record(size_t ri, bool on_side) {
+    const Rec& r = recs[ri];
+    if (pack_split > 0 && ri == pack_cut_rec) { Op& o = push(OP_JOIN); o.epi = 1; tag(o, "other", "join.pack", 0, 0); }
+    const size_t first = ops->size();
+    leaf_scope = on_side;
+    if (r.type == 0) emit_conv_fwd(convs[r.idx]); else emit_pool_fwd(pools[r.idx]);
+    leaf_scope = false;
+    if (on_side && s2_interleave)
+      for (size_t i = first; i < ops->size(); ++i)
+        if ((*ops)[i].leaf == 1) { if (s2_chain_started) (*ops)[i].leaf = 3; s2_chain_started = true; }
   }
-  void emit_pack_join() {
-    if (pack_split > 0) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
+  bool s2_chain_started = false;
+  void emit_forward_records() {
+    const bool beside = g.fusion == 2 && s2_overlap && s2_recs > 0;
+    s2_chain_started = false;
+    size_t ri = 0;
+    if (beside && s2_interleave && pack_cut_rec >= concat_rec) {
+      size_t a = s2_recs, b = 0;  // the first stream's next record, the second stream's
+      while (a < concat_rec || b < s2_recs) {
+        if (a < concat_rec) emit_record(a++, false);
+        if (b < s2_recs) emit_record(b++, true);
+      }
+      ri = concat_rec;
+    }
+    for (; ri < recs.size(); ++ri) {
+      if (beside && ri == concat_rec) { Op& o = push(OP_JOIN); tag(o, "other", "join", 0, 0); }
+      emit_record(ri, beside && ri < s2_recs);
+    }
   }
 
   // ---------------------------------------------------------------- gradient buckets (data-parallel overlap)
@@ -1398,6 +1415,8 @@ struct Builder {
   int* prefix_dev = nullptr;
   int total_rows = 0;          // rows of the pack launch behind the split (all rows without a split)
   int pack_split = 0, pack_rows0 = 0;
+  size_t pack_cut_rec = 0;     // the first forward record whose weights the second pack launch holds
+  static constexpr double PACK_EARLY_ELEMS = 3.0e6;
 
   void emit_all() {
     // pack tables live in the workspace
@@ -1405,11 +1424,32 @@ struct Builder {
     // the side stream beside the input conversion and the stem convolution (pack_split descriptors / pack_rows0 rows in front;
     // the row prefix restarts at 0 behind the split).
     pack_split = 0;
-    if (!recs.empty() && recs[0].type == 0 && getenv("DMM_NO_PACK_SPLIT") == nullptr) {
-      const ConvRec& c0 = convs[recs[0].idx];
-      for (auto& ph : c0.phases) pack_split = std::max(pack_split, ph.pack + 1);
-      for (int s = 0; s < c0.nseg; ++s) if (c0.seg[s].dgrad != DG_NONE) pack_split = std::max(pack_split, c0.dpack[s] + 1);
-      if (pack_split >= (int)P.packs.size()) pack_split = 0;
+    pack_cut_rec = recs.size();
+    if (!recs.empty() && getenv("DMM_NO_PACK_SPLIT") == nullptr) {
+      // The cut: the first record behind the point where PACK_EARLY_ELEMS weight elements have been seen (d121/d201: inside dense
+      // block 3), not in front of the concat module.  DMM_PACK_CUT=<record index> moves it (1 = the round-3 split behind the stem).
+      const char* pc = getenv("DMM_PACK_CUT");
+      size_t cut = recs.size();
+      if (pc) cut = (size_t)std::max(1, atoi(pc));
+      else {
+        double elems = 0;
+        for (size_t ri = 0; ri < recs.size(); ++ri) {
+          if (recs[ri].type != 0) continue;
+          const ConvRec& c = convs[recs[ri].idx];
+          elems += (double)c.N * c.Kin * c.R * c.S;
+          if (elems > PACK_EARLY_ELEMS && ri + 1 > concat_rec) { cut = ri + 1; break; }
+        }
+      }
+      cut = std::min(cut, recs.size());
+      auto packs_of = [&](const ConvRec& c, int& lo, int& hi) {
+        for (auto& ph : c.phases) { lo = std::min(lo, ph.pack); hi = std::max(hi, ph.pack); }
+        for (int s = 0; s < c.nseg; ++s) if (c.seg[s].dgrad != DG_NONE) { lo = std::min(lo, c.dpack[s]); hi = std::max(hi, c.dpack[s]); }
+      };
+      int lo0 = 1 << 30, hi0 = -1, lo1 = 1 << 30, hi1 = -1;
+      for (size_t ri = 0; ri < recs.size(); ++ri)
+        if (recs[ri].type == 0) { if (ri < cut) packs_of(convs[recs[ri].idx], lo0, hi0); else packs_of(convs[recs[ri].idx], lo1, hi1); }
+      // (the descriptors of the early records must be a prefix of the table: they are, records and packs are created in one order)
+      if (hi0 >= 0 && hi1 >= 0 && hi0 < lo1 && hi0 + 1 < (int)P.packs.size()) { pack_split = hi0 + 1; pack_cut_rec = cut; }
     }
     P.pack_prefix.clear();
     total_rows = 0;

@@ -42,7 +42,8 @@ struct PackArgs { const PackDesc* descs; const int* prefix; int ndesc, total_row
 struct Op {
   int kind;
   int epi;
-  int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it)
+  int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it): 1 side stream, forked from
+                   // the main stream; 3 side stream, continuing the chain of the launch in front of it there (no fork); 2 pack stream
   int signal;      // gradient bucket event to record behind this launch on the stream it ran on (-1: none)
   int impl;        // kernel family (enum Impl) chosen for this launch when the plan was built
   double flops;    // algorithmic 2*MACs of this launch (reference formulation)

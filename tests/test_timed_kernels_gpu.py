@@ -25,11 +25,11 @@ def lab():
     return gpu_lab
 
 
-def plan_labels(plan):
+def plan_labels(plan, lists=(0, 1)):
     from dmmfods_amd import _lib
     L = _lib.lib()
     out = []
-    for which in (0, 1):
+    for which in lists:
         for i in range(L.dmm_plan_profile_num_ops(plan.handle, which)):
             label, fl, by = C.c_char_p(), C.c_double(), C.c_double()
             _lib.check(L.dmm_plan_profile_op(plan.handle, which, i, C.byref(label), C.byref(fl), C.byref(by)))
@@ -409,3 +409,52 @@ def test_head_forward_phases_in_one_launch(dtype, monkeypatch):
     assert (nl[0], nl[1]) == (1, 4), nl
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+def test_mid_fusion_forward_interleaves_the_encoders_and_packs_late_weights_aside(monkeypatch):
+    """Round 4: with mid fusion the two encoders' forward records are emitted alternately (the second stream's as one chain on the side
+    stream), the weights of the early layers are packed on the launch stream and the rest by a launch on a stream of its own, joined
+    in front of the first layer that needs them (plan.cpp emit_forward_records / pack_cut_rec).  Against the round-3 order - one
+    encoder after the other, everything but the stem's weights packed behind a join after the stem - the logits must be EQUAL and
+    the gradients equal up to the order of the fp32 atomics: a missing dependency between the three streams would show here."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(2, 2, 2), num_init_features=64, concat_before_block_num=2, stream_2_in_channels=3)
+    model = _model(arch, "fp16")
+    model.load_state_dict(R.make_state(arch, seed=5))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 128, 192, seed=9))
+    res, labels = {}, {}
+    for old in (0, 1, 0):
+        if old:
+            monkeypatch.setenv("DMM_PACK_CUT", "1")
+            monkeypatch.setenv("DMM_NO_S2_INTERLEAVE", "1")
+        else:
+            monkeypatch.setenv("DMM_PACK_CUT", "16")   # (the test net is far below the element count that places the cut by itself)
+            monkeypatch.delenv("DMM_NO_S2_INTERLEAVE", raising=False)
+        model._plans.clear()
+        for _ in range(2):   # the second pass runs with the streams and events of the first already made
+            with torch.no_grad():
+                logits = model(rgb, lidar).clone()
+            model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        res.setdefault(old, []).append((logits, model.grad_arena.clone().double()))
+        labels[old] = plan_labels(model._last[0], lists=(0,))   # the training forward list
+    monkeypatch.delenv("DMM_PACK_CUT", raising=False)
+    monkeypatch.delenv("DMM_NO_S2_INTERLEAVE", raising=False)
+    model._plans.clear()
+    new, oldl = labels[0], labels[1]
+    assert sorted(l for l in new if not l.startswith(("other", "pack"))) == sorted(l for l in oldl if not l.startswith(("other", "pack")))
+    s1 = [i for i, l in enumerate(new) if "/f.b1." in l]
+    s2 = [i for i, l in enumerate(new) if "/stream_2_f.b1." in l]
+    assert s1 and s2 and min(s1) < max(s2) and min(s2) < max(s1), "the encoders' records are not interleaved"
+    o1 = [i for i, l in enumerate(oldl) if "/f.b1." in l]
+    o2 = [i for i, l in enumerate(oldl) if "/stream_2_f.b1." in l]
+    assert max(o2) < min(o1)
+    jp = [i for i, l in enumerate(new) if l.endswith("join.pack")]
+    assert len(jp) == 1 and jp[0] > max(s1 + s2), (jp, max(s1 + s2))
+    (l0, g0), (l0b, g0b) = res[0]
+    (l1, g1), = res[1]
+    assert torch.isfinite(l0).all() and float(l0.abs().max()) > 0
+    assert torch.equal(l0, l1) and torch.equal(l0, l0b), float((l0 - l1).abs().max())
+    for a, b in ((g0, g1), (g0, g0b)):
+        assert ((a - b).norm() / b.norm()).item() < 2e-3

@@ -33,7 +33,7 @@ def main(path):
         byq[r["Queue_Id"]].append(r)
     for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         rs.sort(key=lambda r: r["s"])
-        gaps = [rs[i + 1]["s"] - rs[i]["e"] for i in range(len(rs) - 1)]
+        gaps = [rs[i + 1]["s"] - rs[i]["e"] for i in range(len(rs) - 1)] or [0]
         pos = sorted(g for g in gaps if g > 0)
         print(f"queue {q}: {len(rs)} kernels, busy {sum(r['e'] - r['s'] for r in rs) / 1e6:.2f} ms, gaps {sum(pos) / 1e6:.2f} ms "
               f"(median {sorted(gaps)[len(gaps) // 2] / 1e3:.1f} us, {sum(1 for g in gaps if g > 20000)} above 20 us, largest {max(gaps) / 1e3:.0f} us)")
