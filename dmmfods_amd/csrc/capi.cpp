@@ -246,9 +246,9 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_POOL: e = launch_maxpool_fwd(o.mp, dt, lst); break;
       case OP_POOLBWD: e = launch_maxpool_bwd(o.mpb, dt, lst); break;
       case OP_BCE: e = launch_bce_metrics(o.bce, dt, lst); break;
-      case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, lst); break;
+      case OP_PACK: e = launch_pack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, lst, o.pk.tdescs, o.pk.tiles, o.pk.nt1, o.pk.nt9); break;
       case OP_APPLYCORR: e = launch_apply_corr(o.ac, dt, lst); break;
-      case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, lst); break;
+      case OP_UNPACK: e = launch_unpack(o.pk.descs, o.pk.prefix, o.pk.ndesc, o.pk.total_rows, dt, o.pk.grad_scale, lst, o.pk.tdescs, o.pk.tiles, o.pk.nt1, o.pk.nt9); break;
       default: join(); return fail(DMM_ERR_STATE, "unknown op");
     }
     if (host_prof && o.kind < 32) { const double t2 = now(); hp_fork[o.kind] += hp_t1 - hp_t0; hp_launch[o.kind] += t2 - hp_t1; hp_n[o.kind]++; }

@@ -408,6 +408,7 @@ struct Builder {
       fill_pack_seg(pd.seg[0], taps, c.N, kc, 0, BK);
     }
     pd.st = 1;
+    pd.rs = (int)RS;
     pd.w += base_off;
     {
       const int cs = dgrad_seg ? c.seg[seg_index].C : 0;
@@ -1222,6 +1223,67 @@ struct Builder {
     }
   }
 
+  // -------------------------------------------------------------------------------- pack / unpack tile lists (pointwise.hip)
+  // Descriptors [begin, end) of `v` that the tile kernels can take, as groups of consecutive descriptors sharing one master tensor:
+  // one K segment that spans the whole master, whole 32-channel groups, 1x1 or 3x3, the master contiguous along (k, tap) or (n, tap),
+  // and every master tap covered by the group (the parity phases of a ConvTranspose together).  Marks PackDesc::tiled and appends the
+  // tiles - 1x1 masters first, then 3x3 (one launch per instantiation) - with descriptor indices relative to `v`.
+  const bool pack_tiles_on = getenv("DMM_NO_PACK_TILES") == nullptr;
+  void make_tiles(std::vector<PackDesc>& v, size_t begin, size_t end, std::vector<PackTile>& out, int& nt1, int& nt9) {
+    nt1 = nt9 = 0;
+    for (size_t i = begin; i < end; ++i) v[i].tiled = 0;
+    if (dtype == DT_F32 || !pack_tiles_on) return;
+    std::vector<PackTile> t9;
+    for (size_t i = begin; i < end;) {
+      const PackDesc a = v[i];
+      auto same = [&](const PackDesc& b) {
+        return b.w == a.w && b.sn == a.sn && b.sk == a.sk && b.N == a.N && b.Npad == a.Npad && b.nseg == 1 && b.seg[0].Cpad == a.seg[0].Cpad &&
+               b.seg[0].Creal == a.seg[0].Creal && b.seg[0].koff == a.seg[0].koff && (b.dpack != nullptr) == (a.dpack != nullptr) &&
+               (b.gw != nullptr) == (a.gw != nullptr) && b.gw == a.gw;
+      };
+      size_t j = i + 1;
+      while (j < end && j - i < 4 && a.nseg == 1 && same(v[j])) ++j;
+      const int rs = a.rs;
+      const int cls = a.sk == rs ? 1 : (a.sn == rs ? 2 : 0);
+      bool ok = cls != 0 && a.nseg == 1 && a.seg[0].koff == 0 && a.seg[0].Cpad % 32 == 0 && (rs == 1 || rs == 9) && a.st == 1 && a.Npad % 32 == 0;
+      // the segment spans the master: rows of Creal channels x rs taps (class 1), N rows per channel (class 2)
+      ok = ok && (cls == 1 ? a.sn == (long long)a.seg[0].Creal * rs : a.sk == (long long)a.N * rs);
+      unsigned covered = 0;
+      bool exact = true;   // no master tap is written twice (unpack: plain LDS stores instead of atomics)
+      for (size_t k = i; k < j && ok; ++k) {
+        if (v[k].shared_master) ok = false;
+        for (int t = 0; t < v[k].seg[0].ntaps; ++t)
+          for (int q = 0; q < 4; ++q) {
+            const unsigned mt = (v[k].seg[0].tapw[t] >> (8 * q)) & 0xff;
+            if (mt == 0xff) continue;
+            if ((int)mt >= rs) { ok = false; continue; }
+            if (covered & (1u << mt)) exact = false;
+            covered |= 1u << mt;
+          }
+      }
+      ok = ok && covered == (1u << rs) - 1u;
+      if (ok) {
+        for (size_t k = i; k < j; ++k) v[k].tiled = cls;
+        for (int n0 = 0; n0 < a.Npad; n0 += 32)
+          for (int cg = 0; cg < a.seg[0].Cpad / 32; ++cg) {
+            const PackTile pt{(int)i, (int)(j - i) | (exact ? 0x100 : 0), n0, cg};
+            if (rs == 1) { out.push_back(pt); ++nt1; } else { t9.push_back(pt); ++nt9; }
+          }
+      }
+      i = j;
+    }
+    out.insert(out.end(), t9.begin(), t9.end());
+  }
+  static int pack_rows(const PackDesc& pd) {  // rows the generic kernels walk for this descriptor (none once the tile kernels have it)
+    if (pd.tiled) return 0;
+    int chunks = 0;
+    for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
+    return chunks * pd.Npad;
+  }
+  PackTile* ptiles_dev = nullptr;
+  PackTile* utiles_dev = nullptr;
+  int pt_early1 = 0, pt_early9 = 0, pt_late1 = 0, pt_late9 = 0;
+
   // -------------------------------------------------------------------------------- launch lists
   void emit_convert(std::vector<int>& idx) {
     auto one = [&](int buf, int c1, int c2, int which) {
@@ -1250,6 +1312,7 @@ struct Builder {
       o.pk.ndesc = pack_split;
       o.pk.total_rows = pack_rows0;
       o.pk.grad_scale = 1.0f / d.loss_scale;
+      o.pk.tdescs = pack_dev; o.pk.tiles = ptiles_dev; o.pk.nt1 = pt_early1; o.pk.nt9 = pt_early9;
       tag(o, "pack", "early", 0, 0);
     }
     Op& o = push(kind);
@@ -1259,6 +1322,7 @@ struct Builder {
     o.pk.ndesc = (int)P.packs.size() - pack_split;
     o.pk.total_rows = total_rows;
     o.pk.grad_scale = 1.0f / d.loss_scale;
+    o.pk.tdescs = pack_dev; o.pk.tiles = ptiles_dev + pt_early1 + pt_early9; o.pk.nt1 = pt_late1; o.pk.nt9 = pt_late9;
     tag(o, kind == OP_PACK ? "pack" : "unpack", "weights", 0, (double)P.nparams * (4.0 + esz) * 2.0);
   }
   // Mid fusion: the second stream's encoder (records [0, s2_recs)) shares nothing with the first stream's until the concat module
@@ -1306,6 +1370,7 @@ struct Builder {
     int64_t off = 0, n = 0;
     int convs_left = 0, bns_left = 0;
     int first_desc = 0, ndesc = 0, rows = 0;
+    int tile0 = 0, nt1 = 0, nt9 = 0;   // the bucket's range of P.unpack_tiles (descriptor indices relative to P.unpacks)
     int last_main = -1, last_side = -1;
   };
   std::vector<BucketRec> brecs;
@@ -1352,23 +1417,26 @@ struct Builder {
     for (auto& c : convs) brecs[bucket_of(T(c.wname).off)].convs_left++;
     for (auto& b : bns) brecs[bucket_of(b.dgamma - P.grads)].bns_left++;
     // unpack tables: the descriptors that scatter into a master gradient, grouped by bucket
-    P.unpacks.clear(); P.unpack_prefix.clear();
+    P.unpacks.clear(); P.unpack_prefix.clear(); P.unpack_tiles.clear();
     for (size_t bi = 0; bi < brecs.size(); ++bi) {
       BucketRec& bk = brecs[bi];
       bk.first_desc = (int)P.unpacks.size();
       bk.rows = 0;
       for (auto& pd : P.packs) {
         if (pd.gw == nullptr || pd.dpack == nullptr || bucket_of(pd.gw - P.grads) != (int)bi) continue;
-        P.unpack_prefix.push_back(bk.rows);
-        int chunks = 0;
-        for (int s2 = 0; s2 < pd.nseg; ++s2) chunks += pd.seg[s2].nchunks;
-        bk.rows += chunks * pd.Npad;
         P.unpacks.push_back(pd);
       }
       bk.ndesc = (int)P.unpacks.size() - bk.first_desc;
+      bk.tile0 = (int)P.unpack_tiles.size();
+      make_tiles(P.unpacks, (size_t)bk.first_desc, P.unpacks.size(), P.unpack_tiles, bk.nt1, bk.nt9);
+      for (size_t k = (size_t)bk.first_desc; k < P.unpacks.size(); ++k) {
+        P.unpack_prefix.push_back(bk.rows);
+        bk.rows += pack_rows(P.unpacks[k]);
+      }
     }
     unpack_dev = wptr<PackDesc>(P.packs.size() + 1);  // sized by the pack count: identical in the sizing and the bound pass
     unprefix_dev = wptr<int>(P.packs.size() + 1);
+    utiles_dev = wptr<PackTile>(P.unpack_tiles.size() + 1);
   }
   void note_write(int b, int op_index) {
     const Op& o = (*ops)[op_index];
@@ -1378,7 +1446,7 @@ struct Builder {
     if (defer_scope) { deferred_convs.push_back(&c); return; }
     const int b = bucket_of(T(c.wname).off);
     BucketRec& bk = brecs[b];
-    if (--bk.convs_left > 0 || bk.ndesc == 0) return;
+    if (--bk.convs_left > 0 || bk.ndesc == 0) return;   // (ndesc counts the tile kernels' descriptors as well)
     // the bucket's last weight gradient: scatter its packed gradients into the arena right behind it (same stream)
     Op& o = push(OP_UNPACK);
     o.leaf = 1;
@@ -1387,6 +1455,7 @@ struct Builder {
     o.pk.ndesc = bk.ndesc;
     o.pk.total_rows = bk.rows;
     o.pk.grad_scale = 1.0f / d.loss_scale;
+    o.pk.tdescs = unpack_dev; o.pk.tiles = utiles_dev + bk.tile0; o.pk.nt1 = bk.nt1; o.pk.nt9 = bk.nt9;
     tag(o, "unpack", "weights", 0, (double)bk.n * (4.0 + 4.0));
     note_write(b, (int)ops->size() - 1);
   }
@@ -1451,6 +1520,9 @@ struct Builder {
       // (the descriptors of the early records must be a prefix of the table: they are, records and packs are created in one order)
       if (hi0 >= 0 && hi1 >= 0 && hi0 < lo1 && hi0 + 1 < (int)P.packs.size()) { pack_split = hi0 + 1; pack_cut_rec = cut; }
     }
+    P.pack_tiles.clear();
+    make_tiles(P.packs, 0, (size_t)pack_split, P.pack_tiles, pt_early1, pt_early9);
+    make_tiles(P.packs, (size_t)pack_split, P.packs.size(), P.pack_tiles, pt_late1, pt_late9);
     P.pack_prefix.clear();
     total_rows = 0;
     pack_rows0 = 0;
@@ -1458,12 +1530,11 @@ struct Builder {
       const PackDesc& pd = P.packs[i];
       if ((int)i == pack_split && pack_split > 0) { pack_rows0 = total_rows; total_rows = 0; }
       P.pack_prefix.push_back(total_rows);
-      int chunks = 0;
-      for (int s = 0; s < pd.nseg; ++s) chunks += pd.seg[s].nchunks;
-      total_rows += chunks * pd.Npad;
+      total_rows += pack_rows(pd);
     }
     pack_dev = wptr<PackDesc>(P.packs.size());
     prefix_dev = wptr<int>(P.packs.size());
+    ptiles_dev = wptr<PackTile>(P.pack_tiles.size() + 1);
     P.metrics_bytes = (size_t)(2 * g.nc + (size_t)d.batch * 2 * g.nc) * sizeof(double);
     P.metrics = zbptr<double>(P.metrics_bytes / sizeof(double));
 
@@ -1551,6 +1622,8 @@ void plan_bind(dmm_plan* p, void* ws) {
   // upload the pack tables
   hipMemcpy(b.pack_dev, p->packs.data(), p->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   hipMemcpy(b.prefix_dev, p->pack_prefix.data(), p->pack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (!p->pack_tiles.empty()) hipMemcpy(b.ptiles_dev, p->pack_tiles.data(), p->pack_tiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
+  if (!p->unpack_tiles.empty()) hipMemcpy(b.utiles_dev, p->unpack_tiles.data(), p->unpack_tiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
   if (!p->unpacks.empty()) {
     hipMemcpy(b.unpack_dev, p->unpacks.data(), p->unpacks.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
     hipMemcpy(b.unprefix_dev, p->unpack_prefix.data(), p->unpack_prefix.size() * sizeof(int), hipMemcpyHostToDevice);

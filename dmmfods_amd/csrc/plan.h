@@ -37,7 +37,10 @@ enum OpKind { OP_MEMSET = 0, OP_CONVERT, OP_IGEMM, OP_WGRAD, OP_BNFIN, OP_BNBWD,
 
 struct MemsetArgs { void* p; size_t bytes; };
 struct CopyArgs { void* dst; const void* src; size_t bytes; };
-struct PackArgs { const PackDesc* descs; const int* prefix; int ndesc, total_rows; float grad_scale; };
+struct PackArgs {
+  const PackDesc* descs; const int* prefix; int ndesc, total_rows; float grad_scale;
+  const PackDesc* tdescs; const PackTile* tiles; int nt1, nt9;  // tile kernels: descriptor array the tiles index, the range's 1x1 / 3x3 tiles
+};
 
 struct Op {
   int kind;
@@ -102,6 +105,7 @@ struct dmm_plan {
   // unpack tables, grouped by gradient bucket
   std::vector<dmm::PackDesc> unpacks;
   std::vector<int> unpack_prefix;
+  std::vector<dmm::PackTile> pack_tiles, unpack_tiles;  // tile-kernel work lists (pointwise.h PackTile)
   size_t bucket_bytes = 0;
   std::vector<GradBucket> buckets;       // in the order they become ready
   std::vector<void*> bucket_events;      // hipEvent_t, created on first use

@@ -139,7 +139,13 @@ struct PackDesc {
   int shared_master;  // several descriptors add into the same master elements
   long long sn, sk, st;  // master index = n*sn + k*sk + tap*st
   PackSeg seg[2];
+  int rs;             // taps of the master tensor (R * S)
+  int tiled;          // 0: generic pack / unpack kernels; 1: tile kernels, the master is contiguous along (k, tap) for a fixed n (sk == rs);
+                      // 2: tile kernels, contiguous along (n, tap) for a fixed k (sn == rs)
 };
+// One workgroup of the tile kernels (pack_tiles_kernel / unpack_tiles_kernel): 32 rows n x 32 channels x all taps of a master tensor,
+// for the `nsib` consecutive descriptors that share it (the parity phases of a ConvTranspose: together they cover every tap once).
+struct PackTile { int desc, nsib, n0, cg; };   // nsib: count | 0x100 when no master tap is written twice by the group
 
 // Fused backward of a dense layer's 1x1 bottleneck convolution (bw1.hip): the data-gradient launch `c` (EPI_BNBWD) plus the
 // packed weight gradient of the same convolution.
@@ -186,9 +192,10 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
 hipError_t launch_bce_metrics(const BceArgs& a, int dtype, hipStream_t st);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
 hipError_t launch_apply_corr(const ApplyCorrArgs& a, int dtype, hipStream_t st);
-hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st);
+hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st,
+                       const PackDesc* tile_descs = nullptr, const PackTile* tiles_dev = nullptr, int nt1 = 0, int nt9 = 0);
 hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
-                         hipStream_t st);
+                         hipStream_t st, const PackDesc* tile_descs = nullptr, const PackTile* tiles_dev = nullptr, int nt1 = 0, int nt9 = 0);
 
 #if defined(__HIPCC__)
 // ---- the finalize steps, per channel: bodies of bn_finalize_kernel / bn_bwd_finalize_kernel ----

@@ -556,7 +556,144 @@ __global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* descs, cons
   }
 }
 
-hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st) {
+// ---- tile kernels (round 4) ----
+// The generic kernels above gather one master element per load - at stride 36 bytes for 3x3 weights - and find their descriptor by a
+// binary search of dependent loads per THREAD: 0.28 + 0.21 ms at C2, 0.98 + 0.52 ms at C5 for what is a 0.5 / 3 GB copy (10 % of the HBM
+// roofline).  Here a workgroup owns 32 rows x 32 channels x all taps of a master tensor: it reads them as 32 contiguous runs of 32 RS
+// floats (whichever index the master is contiguous along, PackDesc::tiled), turns the tile in LDS and writes whole 64-byte row pieces
+// of the packed layout, 2 KB contiguous per (tap, channel group) - for every descriptor that shares the master (the parity phases of
+// a ConvTranspose), which is read once for all of them.  unpack: the same walk backwards; the phases' contributions meet in LDS, so
+// the master gradient is written once with plain stores (no atomics, nothing to zero).
+constexpr int PT_N = 32;  // rows and channels of a tile
+template <typename T, int RS>
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const PackDesc* __restrict__ descs, const PackTile* __restrict__ tiles) {
+  constexpr int RUN = PT_N * RS, ROW = RUN + 1;
+  __shared__ float tile[PT_N * ROW];
+  const PackTile t = tiles[blockIdx.x];
+  const PackDesc& d = descs[t.desc];
+  const int tid = threadIdx.x;
+  const bool rows_n = d.tiled == 1;                    // LDS rows are n (else channels)
+  const int nvalid = min(PT_N, d.N - t.n0), cvalid = min(PT_N, d.seg[0].Creal - PT_N * t.cg);
+  const int outer_valid = rows_n ? nvalid : cvalid, inner_valid = (rows_n ? cvalid : nvalid) * RS;
+  const long long ostride = rows_n ? d.sn : d.sk;
+  const float* base = d.w + (long long)t.n0 * d.sn + (long long)(PT_N * t.cg) * d.sk;
+  if ((((size_t)base | (size_t)(ostride * 4)) & 15) == 0) {   // 16-byte loads (every tensor of the arena starts on a multiple of 4 floats)
+    for (int idx = tid; idx < PT_N * RUN / 4; idx += 256) {
+      const int o = idx / (RUN / 4), j = (idx - o * (RUN / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < outer_valid && j + 3 < inner_valid) v = *(const f32x4*)(base + o * ostride + j);
+      else if (o < outer_valid)
+        for (int q = 0; q < 4; ++q) if (j + q < inner_valid) v[q] = base[o * ostride + j + q];
+      float* tp = tile + o * ROW + j;   // (ROW is odd: scalar LDS stores)
+      tp[0] = v[0]; tp[1] = v[1]; tp[2] = v[2]; tp[3] = v[3];
+    }
+  } else {
+    for (int idx = tid; idx < PT_N * RUN; idx += 256) {
+      const int o = idx / RUN, j = idx - o * RUN;
+      tile[o * ROW + j] = (o < outer_valid && j < inner_valid) ? base[o * ostride + j] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int nsib = t.nsib & 0xff;
+  for (int sb = 0; sb < nsib; ++sb) {
+    const PackDesc& ds = descs[t.desc + sb];
+    const PackSeg& sg = ds.seg[0];
+    const int cpt = sg.Cpad / 32;
+    for (int u = tid; u < sg.ntaps * (PT_N * 4); u += 256) {
+      const int tap = u / (PT_N * 4), rem = u - tap * (PT_N * 4), nn = rem >> 2, sl = rem & 3;
+      const unsigned tw = sg.tapw[tap];
+      float out[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = sl * 8 + e;
+        const int at = rows_n ? nn * ROW + c * RS : c * ROW + nn * RS;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned mt = (tw >> (8 * q)) & 0xff;
+          if (mt != 0xff) v += tile[at + mt];
+        }
+        out[e] = v;
+      }
+      T* dst = (T*)ds.dst + ((size_t)(tap * cpt + t.cg) * ds.Npad + t.n0 + nn) * 32 + sl * 8;
+      *(typename TT<T>::vec*)dst = f32_to_vec<T>(out);
+    }
+  }
+}
+
+template <int RS>
+__global__ __launch_bounds__(256) void unpack_tiles_kernel(const PackDesc* __restrict__ descs, const PackTile* __restrict__ tiles, float grad_scale) {
+  constexpr int RUN = PT_N * RS, ROW = RUN + 1;
+  __shared__ float tile[PT_N * ROW];
+  const PackTile t = tiles[blockIdx.x];
+  const PackDesc& d = descs[t.desc];
+  const int tid = threadIdx.x;
+  const bool rows_n = d.tiled == 1;
+  const bool exact = (t.nsib & 0x100) != 0;   // every master tap is written by exactly one packed tap of the group: plain LDS stores
+  const int nsib = t.nsib & 0xff;
+  if (!exact) {
+    for (int idx = tid; idx < PT_N * ROW; idx += 256) tile[idx] = 0.f;
+    __syncthreads();
+  }
+  for (int sb = 0; sb < nsib; ++sb) {
+    const PackDesc& ds = descs[t.desc + sb];
+    const PackSeg& sg = ds.seg[0];
+    const int cpt = sg.Cpad / 32;
+    for (int u = tid; u < sg.ntaps * (PT_N * 4); u += 256) {
+      const int tap = u / (PT_N * 4), rem = u - tap * (PT_N * 4), nn = rem >> 2, sl = rem & 3;
+      const unsigned tw = sg.tapw[tap];
+      float in[8];
+      load_f32s<8>(ds.dpack + ((size_t)(tap * cpt + t.cg) * ds.Npad + t.n0 + nn) * 32 + sl * 8, in);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = sl * 8 + e;
+        const int at = rows_n ? nn * ROW + c * RS : c * ROW + nn * RS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned mt = (tw >> (8 * q)) & 0xff;
+          if (mt == 0xff) continue;
+          if (exact) tile[at + mt] = in[e];
+          else atomicAdd(&tile[at + mt], in[e]);   // (LDS; merged taps and phases meet here)
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nvalid = min(PT_N, d.N - t.n0), cvalid = min(PT_N, d.seg[0].Creal - PT_N * t.cg);
+  const int outer_valid = rows_n ? nvalid : cvalid, inner_valid = (rows_n ? cvalid : nvalid) * RS;
+  const long long ostride = rows_n ? d.sn : d.sk;
+  float* base = d.gw + (long long)t.n0 * d.sn + (long long)(PT_N * t.cg) * d.sk;
+  if ((((size_t)base | (size_t)(ostride * 4)) & 15) == 0) {
+    for (int idx = tid; idx < PT_N * RUN / 4; idx += 256) {
+      const int o = idx / (RUN / 4), j = (idx - o * (RUN / 4)) * 4;
+      const float* tp = tile + o * ROW + j;
+      if (o < outer_valid && j + 3 < inner_valid) {
+        const f32x4 v = {tp[0] * grad_scale, tp[1] * grad_scale, tp[2] * grad_scale, tp[3] * grad_scale};
+        *(f32x4*)(base + o * ostride + j) = v;
+      } else if (o < outer_valid) {
+        for (int q = 0; q < 4; ++q) if (j + q < inner_valid) base[o * ostride + j + q] = tp[q] * grad_scale;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < PT_N * RUN; idx += 256) {
+      const int o = idx / RUN, j = idx - o * RUN;
+      if (o < outer_valid && j < inner_valid) base[o * ostride + j] = tile[o * ROW + j] * grad_scale;
+    }
+  }
+}
+
+// A tile range holds the tiles of the 1x1 masters first (nt1), then those of the 3x3 masters (nt9): one launch per instantiation.
+hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, hipStream_t st,
+                       const PackDesc* tile_descs, const PackTile* tiles_dev, int nt1, int nt9) {
+  if (dtype != DT_F32 && tiles_dev != nullptr) {
+    if (dtype == DT_F16) {
+      if (nt1 > 0) hipLaunchKernelGGL((pack_tiles_kernel<f16, 1>), dim3(nt1), dim3(256), 0, st, tile_descs, tiles_dev);
+      if (nt9 > 0) hipLaunchKernelGGL((pack_tiles_kernel<f16, 9>), dim3(nt9), dim3(256), 0, st, tile_descs, tiles_dev + nt1);
+    } else {
+      if (nt1 > 0) hipLaunchKernelGGL((pack_tiles_kernel<bf16, 1>), dim3(nt1), dim3(256), 0, st, tile_descs, tiles_dev);
+      if (nt9 > 0) hipLaunchKernelGGL((pack_tiles_kernel<bf16, 9>), dim3(nt9), dim3(256), 0, st, tile_descs, tiles_dev + nt1);
+    }
+  }
   if (total_rows <= 0) return hipSuccess;
   dim3 grid((total_rows * 4 + 255) / 256), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(pack_kernel<f16>, grid, block, 0, st, descs_dev, prefix_dev, ndesc, total_rows);
@@ -566,7 +703,11 @@ hipError_t launch_pack(const PackDesc* descs_dev, const int* prefix_dev, int nde
 }
 
 hipError_t launch_unpack(const PackDesc* descs_dev, const int* prefix_dev, int ndesc, int total_rows, int dtype, float grad_scale,
-                         hipStream_t st) {
+                         hipStream_t st, const PackDesc* tile_descs, const PackTile* tiles_dev, int nt1, int nt9) {
+  if (dtype != DT_F32 && tiles_dev != nullptr) {
+    if (nt1 > 0) hipLaunchKernelGGL(unpack_tiles_kernel<1>, dim3(nt1), dim3(256), 0, st, tile_descs, tiles_dev, grad_scale);
+    if (nt9 > 0) hipLaunchKernelGGL(unpack_tiles_kernel<9>, dim3(nt9), dim3(256), 0, st, tile_descs, tiles_dev + nt1, grad_scale);
+  }
   if (total_rows <= 0) return hipSuccess;
   dim3 grid((total_rows * 4 + 255) / 256), block(256);
   if (dtype != DT_F32)  // the packed gradient is fp32 for every storage type: only the chunk geometry (BK = 32) matters

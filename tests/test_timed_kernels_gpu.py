@@ -458,3 +458,38 @@ def test_mid_fusion_forward_interleaves_the_encoders_and_packs_late_weights_asid
     assert torch.equal(l0, l1) and torch.equal(l0, l0b), float((l0 - l1).abs().max())
     for a, b in ((g0, g1), (g0, g0b)):
         assert ((a - b).norm() / b.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_pack_and_unpack_tile_kernels_against_the_generic_kernels(dtype, monkeypatch):
+    """Round 4: weights are packed (and packed gradients scattered back) by tile kernels that turn 32 x 32 x taps blocks of a master
+    tensor in LDS (pointwise.hip pack_tiles_kernel / unpack_tiles_kernel: 1x1 and 3x3 tensors, both contiguity classes, the parity
+    phases of a ConvTranspose as one group) instead of one gathered element per load.  Packing is a permutation + conversion, so the
+    logits must be EQUAL to those of the generic kernels (DMM_NO_PACK_TILES=1); every gradient tensor must agree to the noise of the
+    fp32 atomics of the weight-gradient kernels - a wrong tap or channel mapping is an O(1) difference in that tensor."""
+    from oracle import restatement as R
+    arch = R.Arch(growth_rate=32, block_config=(2, 2, 2), num_init_features=64, concat_before_block_num=2, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=21))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=4))
+    res = {}
+    for generic in (0, 1):
+        if generic:
+            monkeypatch.setenv("DMM_NO_PACK_TILES", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_PACK_TILES", raising=False)
+        model._plans.clear()
+        with torch.no_grad():
+            logits = model(rgb, lidar).clone()
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        res[generic] = (logits, {n: p.grad.detach().double().clone() for n, p in model.named_parameters()})
+    monkeypatch.delenv("DMM_NO_PACK_TILES", raising=False)
+    model._plans.clear()
+    (l0, g0), (l1, g1) = res[0], res[1]
+    assert torch.isfinite(l0).all() and float(l0.abs().max()) > 0
+    assert torch.equal(l0, l1), float((l0 - l1).abs().max())
+    worst = max(((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-30)).item() for n in g0)
+    assert all(float(g1[n].abs().max()) > 0 for n in g1)
+    assert worst < 2e-3, worst
