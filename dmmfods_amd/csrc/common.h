@@ -118,6 +118,10 @@ struct ConvArgs {
   short ph_taps0[4][4];    // taps of seg[0] per phase
   short ph_taps1[4][9];    // taps of seg[1] per phase
   signed char ph_py[4], ph_px[4];
+  // cvp.hip, forward: the four parity phases of a ConvTranspose in one launch (nphase = 4; ph_wpack / ph_taps0 / ph_py / ph_px as above,
+  // ph_ntaps = taps of each phase: 1, 2, 2, 4 in some order).  Separate launches of 600 (1200) workgroups each ran two (three) rounds on
+  // the chip's 512 slots, the last one mostly empty; one launch of all phases, longest first, fills them.
+  signed char ph_ntaps[4];
 };
 
 // Weight-gradient GEMM:  dP[chunk][n][k] += sum_m dYeff[m][n] * A[m][k], same A gather as the forward conv.

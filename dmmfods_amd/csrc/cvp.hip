@@ -13,6 +13,7 @@
 //     swizzle as in igemm.hip), prefetched one stage ahead;
 //   * one barrier per stage of 16 MFMAs per wave and nothing but fragment reads and MFMAs between barriers;
 //   * epilogue as in conv3.hip: values staged as T, BatchNorm sums straight from the accumulator layout, parity-strided store.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,10 +41,16 @@ struct CvpArgs {
   ConvArgs c;
   int tiles_y, tiles_x, ntn;  // pixel tiles, 128-column tiles
   int dymin, dxmin;           // origin of the tap box
+  // multi-phase launches (ConvArgs::nphase = 4): workgroups per phase, per XCD and phase (rounded up), the phases longest first, the
+  // origin of each phase's tap box
+  int per, per8;
+  signed char order[4], ph_dymin[4], ph_dxmin[4];
 };
+// What distinguishes the phases of a multi-phase launch (the single-phase launch: the fields of ConvArgs / CvpArgs themselves).
+struct CvpPhase { const void* wpack; const short* taps; int py, px, dymin, dxmin; };
 
 template <typename T, int NTAP>
-__global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
+__device__ __forceinline__ void cvp_body(const CvpArgs& g, const int lbid, const CvpPhase P) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
   constexpr int SLOT = 8, BN = CP_BN, NT = BN / 32;
@@ -60,7 +67,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = lbid % g.ntn;
   int tile = lbid / g.ntn;
   const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
 
   if (tid < BM) {
     const int y = y0 + (tid >> 4), x = x0 + (tid & 15);
-    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + a.py) * a.Wout + x * a.ostride + a.px : -1;
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + P.py) * a.Wout + x * a.ostride + P.px : -1;
   }
 
   // ---- the halo slots of this thread: fixed pixel positions, channel column cx of the current group ----
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   for (int i = 0; i < NX; ++i) {
     const int hp = px0 + 16 * i;
     const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
-    const int y = y0 + g.dymin + hy, x = x0 + g.dxmin + hx;
+    const int y = y0 + P.dymin + hy, x = x0 + P.dxmin + hx;
     if (hp < CP_HH * CP_HW) {
       xin |= 1u << i;
       if ((unsigned)y < (unsigned)sx.Hs && (unsigned)x < (unsigned)sx.Ws) okx |= 1u << i;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   };
 
   // ---- weights: a stage = chunks (c0, c0 + 1) x 128 columns = 2 x 8 KB contiguous; thread -> pieces tid, tid + 256 of each ----
-  const T* wp = (const T*)a.wpack;
+  const T* wp = (const T*)P.wpack;
   const int cpt = sx.Cpad / 32;  // chunks per tap
   // two register sets, filled two stages ahead: a stage's MFMAs are shorter than an L2 round trip.  Every load is issued
   // unconditionally (past the end: a valid chunk again) so that the compiler's counted waits leave the other set in flight.
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
   int aoff[NTAP];
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
-    const int tw = sx.taps[t];
-    const int dy = (int)(signed char)(tw & 0xff) - g.dymin, dx = (int)(signed char)((tw >> 8) & 0xff) - g.dxmin;
+    const int tw = P.taps[t];
+    const int dy = (int)(signed char)(tw & 0xff) - P.dymin, dx = (int)(signed char)((tw >> 8) & 0xff) - P.dxmin;
     aoff[t] = (2 * wave + (r >> 4) + dy) * CP_RP + ((r & 15) + dx) * CP_PP + h * 16;
   }
   const int bsw = (r >> 2) & 3;
@@ -228,6 +234,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
       atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + n0 + col, s);
     }
   }
+}
+
+template <typename T, int NTAP>
+__global__ __launch_bounds__(NTHREADS, 2) void cvp_kernel(const CvpArgs g) {
+  const CvpPhase P = {g.c.wpack, g.c.seg[0].taps, g.c.py, g.c.px, g.dymin, g.dxmin};
+  cvp_body<T, NTAP>(g, xcd_remap(blockIdx.x, gridDim.x), P);
+}
+
+// All parity phases of a ConvTranspose in one launch.  Workgroup b runs on XCD b % 8 and is the (b / 8)-th the XCD is handed: the
+// phases are dealt in the order g.order (most taps first), per8 workgroups per XCD and phase, and inside a phase an XCD owns a
+// contiguous range of the tile order (as xcd_remap gives a single-phase launch).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void cvp_multi_kernel(const CvpArgs g) {
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int slot = q / g.per8, j = q - slot * g.per8;
+  const int lbid = xcd * g.per8 + j;
+  if (lbid >= g.per) return;   // (workgroup-uniform: the rounding of per8)
+  const int ph = g.order[slot];
+  const CvpPhase P = {g.c.ph_wpack[ph], g.c.ph_taps0[ph], g.c.ph_py[ph], g.c.ph_px[ph], g.ph_dymin[ph], g.ph_dxmin[ph]};
+  const int nt = g.c.ph_ntaps[ph];
+  if (nt == 4) cvp_body<T, 4>(g, lbid, P);
+  else if (nt == 2) cvp_body<T, 2>(g, lbid, P);
+  else cvp_body<T, 1>(g, lbid, P);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -500,6 +529,29 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st);
 
 // Takes a forward launch (EPI_STORE) with one plain segment of a multiple of 128 BN+ReLU-normalised input channels whose 1, 2 or
 // 4 taps lie in a 2x2 box, a multiple of 128 padded output columns, 16-bit storage.  Returns hipErrorNotSupported otherwise.
+static bool cvp_tap_box(const short* taps, int ntaps, int& dymin, int& dxmin) {
+  int dymax = -128, dxmax = -128;
+  dymin = 127; dxmin = 127;
+  for (int t = 0; t < ntaps; ++t) {
+    const int dy = (int)(signed char)(taps[t] & 0xff), dx = (int)(signed char)((taps[t] >> 8) & 0xff);
+    dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax; dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+  }
+  return dymax - dymin <= 1 && dxmax - dxmin <= 1;
+}
+
+template <typename T>
+static hipError_t launch_cvp_multi_t(const CvpArgs& g, int nwg, hipStream_t st) {
+  auto kern = cvp_multi_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), CP_LDS, st, g);
+  return hipGetLastError();
+}
+
 hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (!family_on(g_cvp, IMPL_CVP) || dtype == DT_F32) return hipErrorNotSupported;
   if (epi == EPI_BNBWD) return launch_cvd(a, dtype, st);
@@ -507,6 +559,32 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   const Seg& x = a.seg[0];
   if (x.mode != G_PLAIN || x.istride != 1 || x.Hs != a.Ho || x.Ws != a.Wo || x.scale == nullptr || x.C % CP_CA || x.Cpad != x.C)
     return hipErrorNotSupported;
+  if (a.nphase != 0) {   // the parity phases of a ConvTranspose in one launch
+    if (a.nphase != 4 || a.ostride != 2 || a.Npad % CP_BN || a.out == nullptr) return hipErrorNotSupported;
+    CvpArgs g;
+    int nt[4];
+    for (int ph = 0; ph < 4; ++ph) {
+      nt[ph] = a.ph_ntaps[ph];
+      int dy0, dx0;
+      if ((nt[ph] != 1 && nt[ph] != 2 && nt[ph] != 4) || a.ph_wpack[ph] == nullptr || !cvp_tap_box(a.ph_taps0[ph], nt[ph], dy0, dx0) ||
+          a.ph_py[ph] < 0 || a.ph_py[ph] > 1 || a.ph_px[ph] < 0 || a.ph_px[ph] > 1)
+        return hipErrorNotSupported;
+      g.ph_dymin[ph] = (signed char)dy0; g.ph_dxmin[ph] = (signed char)dx0;
+    }
+    if (g_ctl.dry) return hipSuccess;
+    g.c = a;
+    g.dymin = g.dxmin = 0;
+    g.tiles_y = (a.Ho + CP_TH - 1) / CP_TH;
+    g.tiles_x = (a.Wo + CP_TW - 1) / CP_TW;
+    g.ntn = a.Npad / CP_BN;
+    g.per = a.B * g.tiles_y * g.tiles_x * g.ntn;
+    g.per8 = (g.per + 7) / 8;
+    int idx[4] = {0, 1, 2, 3};
+    std::stable_sort(idx, idx + 4, [&](int p, int q) { return nt[p] > nt[q]; });   // most taps first
+    for (int k = 0; k < 4; ++k) g.order[k] = (signed char)idx[k];
+    const int nwg = 8 * g.per8 * 4;
+    return dtype == DT_F16 ? launch_cvp_multi_t<f16>(g, nwg, st) : launch_cvp_multi_t<bf16>(g, nwg, st);
+  }
   if (x.ntaps != 1 && x.ntaps != 2 && x.ntaps != 4) return hipErrorNotSupported;
   if (x.ntaps == 1 && a.ostride == 1) return hipErrorNotSupported;  // plain 1x1 convolutions stay with igemm's lean path
   if (a.Npad % CP_BN || a.out == nullptr) return hipErrorNotSupported;

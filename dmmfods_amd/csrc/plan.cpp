@@ -611,6 +611,35 @@ struct Builder {
         }
       }
     }
+    // The four parity phases of a ConvTranspose (1, 2, 2, 4 taps), all on cvp.hip: ONE launch.  A phase of the first decoder stage is 600
+    // workgroups of 128 x 128 outputs for 512 slots on the chip (two per CU) - two rounds, the second 17 % full; 1200 in the second stage - three
+    // rounds.  One launch deals the 2400 (4800) workgroups of all phases, the 4-tap phase first, and the slots stay full.
+    if (c.phases.size() == 4 && c.nseg == 1 && c.transposed && ops->size() >= 4 && getenv("DMM_NO_CVP_MERGE") == nullptr) {
+      const size_t first = ops->size() - 4;
+      bool ok = true;
+      for (size_t k = first; k < ops->size(); ++k) {
+        const Op& po = (*ops)[k];
+        ok = ok && po.kind == OP_IGEMM && po.epi == EPI_STORE && po.impl == IMPL_CVP && po.c.nseg == 1 && po.c.seg[0].ntaps <= 4 &&
+             po.c.nphase == 0 && po.leaf == (*ops)[first].leaf && po.c.out == (*ops)[first].c.out && po.c.seg[0].src == (*ops)[first].c.seg[0].src;
+      }
+      if (ok) {
+        Op merged = (*ops)[first];
+        merged.c.nphase = 4;
+        merged.flops = 0; merged.bytes = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+          const Op& po = (*ops)[first + ph];
+          merged.c.ph_ntaps[ph] = (signed char)po.c.seg[0].ntaps;
+          for (int t = 0; t < 4; ++t) merged.c.ph_taps0[ph][t] = po.c.seg[0].taps[t < po.c.seg[0].ntaps ? t : 0];
+          merged.c.ph_wpack[ph] = po.c.wpack;
+          merged.c.ph_py[ph] = (signed char)po.c.py; merged.c.ph_px[ph] = (signed char)po.c.px;
+          merged.flops += po.flops; merged.bytes += po.bytes;
+        }
+        if (igemm_pick(merged.c, dtype, EPI_STORE, d.use_mfma != 0) == IMPL_CVP) {
+          ops->resize(first);
+          ops->push_back(merged);
+        }
+      }
+    }
   }
 
   void fill_grad_seg(Seg& s, int buf, int ch0, int C, const std::vector<Tap>& taps, int istride) {

@@ -493,3 +493,33 @@ def test_pack_and_unpack_tile_kernels_against_the_generic_kernels(dtype, monkeyp
     worst = max(((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-30)).item() for n in g0)
     assert all(float(g1[n].abs().max()) > 0 for n in g1)
     assert worst < 2e-3, worst
+
+
+def test_decoder_transposed_convolution_phases_in_one_launch(monkeypatch):
+    """Round 4: the four output-parity phases (1, 2, 2, 4 taps) of each decoder ConvTranspose run as ONE cvp.hip launch that deals the
+    workgroups of all phases, most taps first (separate launches of 600 / 1200 workgroups left the last round on the chip's 512 slots
+    mostly empty).  Same arithmetic per phase, no float atomics on stored values: against sixteen launches (DMM_NO_CVP_MERGE=1) the
+    logits must be EQUAL bit for bit.  densenet121 widths (the decoder's 1024 / 512 / 256 / 128 channels are what cvp.hip takes)."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=2, stream_2_in_channels=3)
+    model = _model(arch, "fp16")
+    model.load_state_dict(R.make_state(arch, seed=2))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=6))
+    outs, nl = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_CVP_MERGE", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_CVP_MERGE", raising=False)
+        model._plans.clear()
+        with torch.no_grad():
+            outs[off] = model(rgb, lidar).clone()
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0], lists=(0,))
+        nl[off] = sum(lab.startswith("cvp.store") for lab in labels)
+    monkeypatch.delenv("DMM_NO_CVP_MERGE", raising=False)
+    model._plans.clear()
+    assert (nl[0], nl[1]) == (4, 16), nl
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
