@@ -218,6 +218,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
   load_f32s<SLOT>(a.invstd + c, istd);
 #pragma unroll
   for (int i = 0; i < SLOT; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+  // per-thread partial sums in fp32, moved to the fp64 accumulators every 8 pixels (round 4: two conversions and two fp64 adds per ELEMENT
+  // were a third of this kernel's vector time, and it is one of the two launches the end of the step waits for - the stem's leaves)
+  float f1[SLOT], f2[SLOT];
+#pragma unroll
+  for (int i = 0; i < SLOT; ++i) { f1[i] = 0.f; f2[i] = 0.f; }
+  int pending = 0;
   const int npix = a.B * a.H0 * a.W0;
   const T* y0 = (const T*)a.y0;
   const T* gp = (const T*)a.gpool;
@@ -265,12 +271,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) {
         const float dz = (fmaf(yf[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
-        s1[i] += (double)dz;
-        s2[i] += (double)(dz * ((yf[i] - mu[i]) * istd[i]));
+        f1[i] += dz;
+        f2[i] = fmaf(dz, (yf[i] - mu[i]) * istd[i], f2[i]);
         o[i] = sc[i] * dz;
       }
       *(V*)(gy0 + (size_t)p * a.ld0 + c) = f32_to_vec<T>(o);
+      if (++pending == 8) {
+        pending = 0;
+#pragma unroll
+        for (int i = 0; i < SLOT; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; f1[i] = 0.f; f2[i] = 0.f; }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < SLOT; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; }
   }
   block_channel_reduce<SLOT>(red, a.C, c, s1, s2, a.red1, a.red2, a.stat_stride);
 }
@@ -280,7 +293,8 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.H0 * a.W0;
   int grid = (npix + rpb - 1) / rpb;
-  if (grid > 2048) grid = 2048;  // 8 workgroups per CU: every workgroup ends with 2 C fp64 atomics
+  static const int cap = getenv("DMM_MPB_GRID") ? atoi(getenv("DMM_MPB_GRID")) : 2048;
+  if (grid > cap) grid = cap;  // 8 workgroups per CU: every workgroup ends with 2 C fp64 atomics
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, a);
