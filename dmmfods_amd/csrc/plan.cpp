@@ -605,7 +605,14 @@ struct Builder {
           merged.c.ph_py[ph] = (signed char)po.c.py; merged.c.ph_px[ph] = (signed char)po.c.px;
           merged.flops += po.flops; merged.bytes += po.bytes;
         }
-        if (igemm_pick(merged.c, dtype, EPI_STORE, d.use_mfma != 0) == IMPL_CONV3) {
+        const int took = igemm_pick(merged.c, dtype, EPI_STORE, d.use_mfma != 0);
+        if (took == IMPL_CONV3 || took == IMPL_HF) {   // hf.hip (wave-specialised, one phase per workgroup) where its shape fits, else conv3.hip
+          merged.impl = took;
+          if (took == IMPL_HF) {
+            char lb[56];
+            snprintf(lb, sizeof(lb), "hf.store%s", strchr(merged.label, '.') && strstr(merged.label, ".n") ? strstr(merged.label, ".n") : "");
+            snprintf(merged.label, sizeof(merged.label), "%s", lb);
+          }
           ops->resize(first);
           ops->push_back(merged);
         }

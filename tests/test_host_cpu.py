@@ -318,6 +318,12 @@ def test_inline_assembly_loads_are_waited_for_before_use():
                         os.path.join(root, "dmmfods_amd", "csrc", "wg3.hip"), "wg3_kernel"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 violations") == 4, r.stdout     # f16 / bf16 x effective-gradient / materialised
+    # hf.hip (round 4): the same loader pattern; the checker also reports scalar loads with a register offset (the form hipcc built for
+    # a kernel-argument array indexed by the phase: misaligned base, wrong pointer - found at hf.hip's bring-up)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_loads.py"),
+                        os.path.join(root, "dmmfods_amd", "csrc", "hf.hip"), "hf_kernel"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 violations") == 2, r.stdout     # f16 / bf16
 
 
 def test_fold_lane_algebra():

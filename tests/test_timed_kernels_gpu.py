@@ -169,7 +169,7 @@ def _errors(model, logits, met, emu, g_emu, o64, g64):
                 grads=(num / den) ** 0.5, y_grads=(ynum / den) ** 0.5, worst_conv=worst)
 
 
-TIMED_FAMILIES = ("bw1.", "bw1.reduce", "pig.", "conv3.store", "conv3.bnbwd", "wg3.", "wgp.", "cvp.store", "cvp.bnbwd", "wg5.", "thin.logits")
+TIMED_FAMILIES = ("bw1.", "bw1.reduce", "pig.", "conv3.store", "conv3.bnbwd", "wg3.", "wgp.", "cvp.store", "cvp.bnbwd", "wg5.", "thin.logits", "hf.store")
 
 
 @pytest.mark.parametrize("variant,H,W", [("early", 64, 96), ("early", 128, 192), ("mid3", 64, 96), ("mid3", 128, 192)])
@@ -385,7 +385,9 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
 def test_head_forward_phases_in_one_launch(dtype, monkeypatch):
     """Round 4: the four output-parity phases of the head's first convolution (conv3.hip: 2x2 merged taps over the half-resolution
     decoder output + 3x3 stride-2 taps over the raw input) run as ONE launch that walks (tile, phase) pairs.  Same arithmetic per
-    phase, no float atomics on stored values: against four launches (DMM_NO_C3_MERGE=1) the logits must be EQUAL bit for bit."""
+    phase, no float atomics on stored values: against four launches (DMM_NO_C3_MERGE=1) the logits must be EQUAL bit for bit.
+    (DMM_NO_HF=1: where hf.hip takes the launch - 128 decoder channels - conv3.hip's path is what is compared here.)"""
+    monkeypatch.setenv("DMM_NO_HF", "1")
     from oracle import restatement as R
     arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
     model = _model(arch, dtype)
@@ -523,3 +525,39 @@ def test_decoder_transposed_convolution_phases_in_one_launch(monkeypatch):
     assert (nl[0], nl[1]) == (4, 16), nl
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 3e-4), ("bf16", 6e-4)])
+def test_head_first_convolution_wave_specialised_kernel(dtype, tol, monkeypatch):
+    """Round 4: hf.hip - the head's first convolution (reference M:126-127) with one parity phase per 8-wave workgroup, the phase's
+    weights resident in LDS, loader waves filling 64-channel half images beside the matrix waves.  densenet121 widths (128 decoder
+    channels in front of the head: the shape hf.hip takes).  Against conv3.hip's one-launch path (DMM_NO_HF=1) the logits agree to the
+    rounding of a different fp32 accumulation order (the K walk is (half, tap, chunk) instead of (tap, chunk)); two runs of hf.hip
+    are EQUAL (no float atomics on stored values); the launch list names the family."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=8))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=12))
+    outs, nhf, nc3 = {}, {}, {}
+    for k, nohf in (("hf", 0), ("conv3", 1), ("hf2", 0)):
+        if nohf:
+            monkeypatch.setenv("DMM_NO_HF", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_HF", raising=False)
+        model._plans.clear()
+        with torch.no_grad():
+            outs[k] = model(rgb, lidar).clone()
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0], lists=(0,))
+        nhf[k] = sum(lab.startswith("hf.store") and lab.endswith("h.refine0") for lab in labels)
+        nc3[k] = sum(lab.startswith("conv3.store") and lab.endswith("h.refine0") for lab in labels)
+    monkeypatch.delenv("DMM_NO_HF", raising=False)
+    model._plans.clear()
+    assert (nhf["hf"], nc3["hf"], nhf["conv3"], nc3["conv3"]) == (1, 0, 0, 1), (nhf, nc3)
+    assert torch.isfinite(outs["hf"]).all() and float(outs["hf"].abs().max()) > 0
+    assert torch.equal(outs["hf"], outs["hf2"]), "hf.hip is not reproducible"
+    rel = ((outs["hf"].double() - outs["conv3"].double()).norm() / outs["conv3"].double().norm()).item()
+    print(f"hf.hip vs conv3.hip ({dtype}): logits rel L2 {rel:.3e}")
+    assert rel < tol, rel

@@ -138,6 +138,20 @@ def check_kernel(name, lines):
     return nloads, sorted(violations)
 
 
+def scalar_offset_loads(name, lines):
+    """Scalar loads whose address is  base + SGPR offset (+ immediate).  hipcc (ROCm 7.2) built one for `args.ptr[phase]` - a kernel
+    argument array indexed by a run-time scalar - as base = kernarg + phase, offset = 7 * phase + 0x278: a base that is not dword-aligned,
+    whose low two bits the scalar memory unit ignores, so phases 1-3 of hf.hip read a wrong pointer (HSA_STATUS_ERROR_MEMORY_APERTURE_
+    VIOLATION at bring-up).  The checked kernels select such values from constant-index copies instead; any register-offset scalar load
+    in them is reported."""
+    out = []
+    for no, text in enumerate(lines, 1):
+        t = text.split(";")[0].strip()
+        if re.match(r"s_(buffer_)?load_dword\w*\s+s\S+,\s*s\[\d+:\d+\],\s*s\d+", t):
+            out.append(f"{name}: line {no}: `{t}` is a scalar load with a register offset (run-time index into a kernel argument?)")
+    return out
+
+
 def main():
     text = device_asm(sys.argv[1])
     want = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -149,6 +163,7 @@ def main():
             continue
         body = k.split("s_endpgm")[0].splitlines()
         n, v = check_kernel(m.group(1), body)
+        v += scalar_offset_loads(m.group(1), body)
         total += n
         bad += v
         if n:
