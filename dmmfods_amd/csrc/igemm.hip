@@ -764,6 +764,7 @@ hipError_t launch_thin_logits(const ConvArgs& a, int dtype, int epi, hipStream_t
 hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st);        // conv3.hip
 hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st);          // cvp.hip
 hipError_t launch_hf(const ConvArgs& a, int dtype, int epi, hipStream_t st);           // hf.hip
+hipError_t launch_cf(const ConvArgs& a, int dtype, int epi, hipStream_t st);           // cf.hip
 hipError_t launch_pig(const ConvArgs& a, int dtype, int epi, hipStream_t st);          // pig.hip
 
 // One translation unit per storage type (IGEMM_PART = 0 fp32, 1 f16, 2 bf16; see the Makefile): the ~50 kernel instantiations
@@ -795,6 +796,8 @@ static hipError_t dispatch_special(const ConvArgs& a, int dtype, int epi, hipStr
   if ((e = launch_thin_logits(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_HF;     // the head's first convolution, four parity phases in one launch: wave-specialised, phase weights resident in LDS
   if ((e = launch_hf(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+  took = IMPL_CF;     // the dense 3x3 forward on the large maps: wave-specialised, weights resident in LDS
+  if ((e = launch_cf(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_CONV3;  // 3x3 convolutions of the dense layers (16-bit storage): LDS halo tile, prologue once per element
   if ((e = launch_conv3(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_CVP;    // forward of the ConvTranspose parity phases: halo tile per 128-channel group, a tap is a fragment address

@@ -576,7 +576,7 @@ struct Builder {
         o.impl = igemm_pick(a, dtype, c.epi, d.use_mfma != 0);
         const bool c3 = o.impl == IMPL_CONV3, cp = o.impl == IMPL_CVP;
         const char* lcls = o.impl == IMPL_THIN ? "thin.logits" : (o.impl == IMPL_HALO ? "halo.logits" : "igemm.logits");
-        tag(o, ncls(c.epi == EPI_LOGITS ? lcls : (c3 ? "conv3.store" : (cp ? "cvp.store" : (o.impl == IMPL_HALO ? "halo.store" : (o.impl == IMPL_PIG ? "pig.store" : "igemm.store")))), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
+        tag(o, ncls(c.epi == EPI_LOGITS ? lcls : (c3 ? "conv3.store" : (cp ? "cvp.store" : (o.impl == IMPL_CF ? "cf.store" : (o.impl == IMPL_HALO ? "halo.store" : (o.impl == IMPL_PIG ? "pig.store" : "igemm.store"))))), pd.Npad, cb), short_name(c.wname), conv_flops(c, c.phases.size()),
             (src_bytes(c) + out_bytes(c)) / np + w_bytes(c) / np);
       }
       if (c.epi == EPI_LOGITS) {

@@ -324,6 +324,10 @@ def test_inline_assembly_loads_are_waited_for_before_use():
                         os.path.join(root, "dmmfods_amd", "csrc", "hf.hip"), "hf_kernel"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 violations") == 2, r.stdout     # f16 / bf16
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_loads.py"),
+                        os.path.join(root, "dmmfods_amd", "csrc", "cf.hip"), "cf_kernel"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 violations") == 2, r.stdout     # cf.hip (the dense 3x3 forward on the large maps): f16 / bf16
 
 
 def test_fold_lane_algebra():

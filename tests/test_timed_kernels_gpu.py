@@ -72,7 +72,8 @@ def test_parity_phase_weight_gradients_with_deferred_correction(lab, dtype):
 
 PRODUCTION = [  # name, B, H, W, Cin, Cout, R, stride, pad, bn, transposed, family: the launches of BASELINE configs[1] (C2) that run on LDS pipelines
     ("stem 7x7s2 8->64 @1280x1920", 4, 1280, 1920, 8, 64, 7, 2, 3, 0, 0, "conv3"),
-    ("dense 3x3 128->32 @320x480", 4, 320, 480, 128, 32, 3, 1, 1, 1, 0, "conv3"),
+    ("dense 3x3 128->32 @320x480", 4, 320, 480, 128, 32, 3, 1, 1, 1, 0, "cf"),      # large maps: the wave-specialised kernel (cf.hip, round 4)
+    ("dense 3x3 128->32 @160x240", 4, 160, 240, 128, 32, 3, 1, 1, 1, 0, "conv3"),   # 1200 tiles: below cf.hip's threshold of eight per CU
     ("dense 3x3 128->32 @80x120", 4, 80, 120, 128, 32, 3, 1, 1, 1, 0, "conv3"),
     ("dense 1x1 224->128 @320x480", 4, 320, 480, 224, 128, 1, 1, 0, 1, 0, "pig"),
     ("dense 1x1 992->128 @80x120", 4, 80, 120, 992, 128, 1, 1, 0, 1, 0, "pig"),      # K-deep: 16 stages behind counted waits (pig.hip)
