@@ -28,6 +28,9 @@
 #include "common.h"
 #include "gather.h"
 
+#ifndef HF_DBG
+#define HF_DBG 0   // timing experiments only (tools/build_variant.sh): 1 the loaders request nothing, 2 nothing is stored, 8 no MFMA stretch, 64 no epilogue
+#endif
 namespace dmm {
 
 constexpr int HF_TH = 8, HF_TW = 16, HF_HH = 9, HF_HW = 17;
@@ -132,40 +135,74 @@ __global__ __launch_bounds__(HF_NT, 2) void hf_kernel(const HfArgs g) {
     const unsigned char* ubase = (const unsigned char*)sg.src;
     const unsigned char* tbase = (const unsigned char*)sg1.src;
     const unsigned upix = (unsigned)sg.ld * 2u, tpix = (unsigned)sg1.ld * 2u, ucol = (unsigned)cs * 16u;
-    struct Set { V u[H2_NU], t[HF_N1]; unsigned oku, okt; };
+    struct Set { V u[H2_NU], t[HF_N1]; unsigned oku, okt; bool inner; };
+    // Interior tiles (both halos inside the picture: 94 % of C2's) take a path without the per-slot clamps, validity tests and zero
+    // selects - one add per request, the prologue straight to LDS: the loader and the matrix wave of a SIMD share its VALU, and the
+    // ablations (profiles/r04/ablations.txt section 15) put the loader side alone at 0.56 ms of the launch's 0.9.
+    unsigned cu[H2_NU], c1[HF_N1];   // byte offsets of this thread's slots relative to the halo's first pixel
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) cu[i] = (unsigned)(hyu[i] * sg.Ws + hxu[i]) * upix + ucol;
+#pragma unroll
+    for (int i = 0; i < HF_N1; ++i) c1[i] = (unsigned)(hy1[i] * sg1.Ws + hx1[i]) * tpix;
     auto issue = [&](Set& R, int item) {   // branch-free: clamped addresses, zeroed at the write if outside; past the end: the last item again
       int b, y0, x0;
       origin(item, b, y0, x0);
+      const int yb = y0 + dymin0, xb = x0 + dxmin0, yt = 2 * y0 + dymin1, xt = 2 * x0 + dxmin1;
+      // (bitwise: ONE condition, one branch - with short-circuit tests the compiled code carried a flag from several exits into a second
+      // branch, a shape in which tools/check_asm_loads.py cannot tell the two paths apart)
+      R.inner = (int)(yb >= 0) & (int)(xb >= 0) & (int)(yb + HF_HH <= sg.Hs) & (int)(xb + HF_HW <= sg.Ws) & (int)(yt >= 0) & (int)(xt >= 0) &
+                (int)(yt + HF_HH1 <= sg1.Hs) & (int)(xt + HF_HW1 <= sg1.Ws);
+      // the offsets are chosen in the branch, the requests are ONE sequence behind it (no inline-assembly load inside a branch: the
+      // compiled if / else carries a flag between blocks, which the ISA checker cannot follow)
+      unsigned ou[H2_NU], ot[HF_N1];
       R.oku = 0; R.okt = 0;
-      const int yb = y0 + dymin0, xb = x0 + dxmin0, row0 = b * sg.Hs;
+      if (R.inner) {   // (workgroup-uniform)
+        const unsigned ub = (unsigned)((b * sg.Hs + yb) * sg.Ws + xb) * upix, tb = (unsigned)((b * sg1.Hs + yt) * sg1.Ws + xt) * tpix;
 #pragma unroll
-      for (int i = 0; i < H2_NU; ++i) {
-        const int sy = yb + hyu[i], sx = xb + hxu[i];
-        if (px0 + 16 * i < HF_HH * HF_HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws) R.oku |= 1u << i;
-        const unsigned pix = (unsigned)((row0 + min(max(sy, 0), sg.Hs - 1)) * sg.Ws + min(max(sx, 0), sg.Ws - 1));
-        hf_load(R.u[i], pix * upix + ucol, ubase);
-      }
-      const int yt = 2 * y0 + dymin1, xt = 2 * x0 + dxmin1, row1 = b * sg1.Hs;
+        for (int i = 0; i < H2_NU; ++i) ou[i] = ub + cu[i];
 #pragma unroll
-      for (int i = 0; i < HF_N1; ++i) {
-        const int sy = yt + hy1[i], sx = xt + hx1[i];
-        if (lt + HF_NL * i < HF_NS1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws) R.okt |= 1u << i;
-        const unsigned pix = (unsigned)((row1 + min(max(sy, 0), sg1.Hs - 1)) * sg1.Ws + min(max(sx, 0), sg1.Ws - 1));
-        hf_load(R.t[i], pix * tpix, tbase);
+        for (int i = 0; i < HF_N1; ++i) ot[i] = tb + c1[i];
+      } else {
+        const int row0 = b * sg.Hs, row1 = b * sg1.Hs;
+#pragma unroll
+        for (int i = 0; i < H2_NU; ++i) {
+          const int sy = yb + hyu[i], sx = xb + hxu[i];
+          if (px0 + 16 * i < HF_HH * HF_HW && (unsigned)sy < (unsigned)sg.Hs && (unsigned)sx < (unsigned)sg.Ws) R.oku |= 1u << i;
+          ou[i] = (unsigned)((row0 + min(max(sy, 0), sg.Hs - 1)) * sg.Ws + min(max(sx, 0), sg.Ws - 1)) * upix + ucol;
+        }
+#pragma unroll
+        for (int i = 0; i < HF_N1; ++i) {
+          const int sy = yt + hy1[i], sx = xt + hx1[i];
+          if (lt + HF_NL * i < HF_NS1 && (unsigned)sy < (unsigned)sg1.Hs && (unsigned)sx < (unsigned)sg1.Ws) R.okt |= 1u << i;
+          ot[i] = (unsigned)((row1 + min(max(sy, 0), sg1.Hs - 1)) * sg1.Ws + min(max(sx, 0), sg1.Ws - 1)) * tpix;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < H2_NU; ++i) if (!(HF_DBG & 1)) hf_load(R.u[i], ou[i], ubase);
+#pragma unroll
+      for (int i = 0; i < HF_N1; ++i) if (!(HF_DBG & 1)) hf_load(R.t[i], ot[i], tbase);
     };
     V z;
 #pragma unroll
     for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
     auto store = [&](Set& R, int set, bool wait = true) {
-      if (wait) h2_wait(R.u, R.t);
+      if (wait && !(HF_DBG & 1)) h2_wait(R.u, R.t);
       unsigned char* img = smem + set * H2_SET;
+      if (R.inner) {
+#pragma unroll
+        for (int i = 0; i < H2_NU; ++i)
+          if (px0 + 16 * i < HF_HH * HF_HW) *(V*)(img + ldsu[i]) = bn_relu_slot(R.u[i], ku);
+#pragma unroll
+        for (int i = 0; i < HF_N1; ++i)
+          if (lt + HF_NL * i < HF_NS1) *(V*)(img + H2_U + (lt + HF_NL * i) * 16) = bn_relu_slot(R.t[i], kt);
+      } else {
 #pragma unroll
       for (int i = 0; i < H2_NU; ++i)
         if (px0 + 16 * i < HF_HH * HF_HW) *(V*)(img + ldsu[i]) = ((R.oku >> i) & 1) ? bn_relu_slot(R.u[i], ku) : z;   // zero padding AFTER the prologue
 #pragma unroll
       for (int i = 0; i < HF_N1; ++i)
         if (lt + HF_NL * i < HF_NS1) *(V*)(img + H2_U + (lt + HF_NL * i) * 16) = ((R.okt >> i) & 1) ? bn_relu_slot(R.t[i], kt) : z;
+      }
     };
 #pragma unroll
     for (int e = 0; e < SLOT; ++e) asm volatile("" : "+v"(ku.k0[e]), "+v"(ku.k1[e]), "+v"(kt.k0[e]), "+v"(kt.k1[e]));
@@ -182,8 +219,7 @@ __global__ __launch_bounds__(HF_NT, 2) void hf_kernel(const HfArgs g) {
       hf_bar();          // barrier k + 1
       issue(R1, k + 3);
     }
-    h2_hold(R0.u, R0.t);
-    h2_hold(R1.u, R1.t);
+    if (!(HF_DBG & 1)) { h2_hold(R0.u, R0.t); h2_hold(R1.u, R1.t); }
     if (nit & 1) {
       store(R0, 0, false);
       hf_bar();
@@ -244,6 +280,7 @@ __global__ __launch_bounds__(HF_NT, 2) void hf_kernel(const HfArgs g) {
       for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
     hf_bar();   // barrier it: image set it & 1 is complete
     const unsigned char* img = smem + (it & 1) * H2_SET;
+    if (!(HF_DBG & 8)) {
 #pragma unroll
     for (int ck = 0; ck < HF_NCH0; ++ck)
 #pragma unroll
@@ -263,6 +300,8 @@ __global__ __launch_bounds__(HF_NT, 2) void hf_kernel(const HfArgs g) {
           const V av = tok1[2 * c + s2] ? ld : z;
           acc[j] = mma16(av, Bf[2 * (HF_NCH0 + c) + s2], acc[j]);
         }
+    }
+    if (HF_DBG & 64) continue;
     // ---- epilogue, wave-local: stage the wave's 64 x 32 tile as T, sums of the stored values from the accumulator layout, 16-byte stores ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -285,7 +324,7 @@ __global__ __launch_bounds__(HF_NT, 2) void hf_kernel(const HfArgs g) {
       const V v = *(const V*)(stg + row * H2_CP + slot * SLOT);
       const int y = y0 + 4 * rb + (row >> 4), x = x0 + (row & 15);
       const size_t pix = ((size_t)b * a.Hout + (size_t)(2 * y + opy)) * a.Wout + (size_t)(2 * x + opx);
-      *(V*)(out + pix * a.ldo + 32 * ct + slot * SLOT) = v;
+      if (!(HF_DBG & 2) || v[0] == (T)12345.f) *(V*)(out + pix * a.ldo + 32 * ct + slot * SLOT) = v;
     }
   }
   if (a.stat_sum != nullptr) {
