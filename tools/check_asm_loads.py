@@ -69,6 +69,12 @@ def check_kernel(name, lines):
             events.append(("insn", addr, no, t))
             events.append(("load", set(range(int(dst.group(1)), int(dst.group(2)) + 1)), no, t))
             continue
+        if in_asm and t.startswith("global_store_dwordx4"):
+            # a hand-written store: vmcnt counts it like a load (gfx9-family: one counter, retired in issue order); it reads its operands
+            # at issue and defines nothing
+            events.append(("insn", regs_of(t.split(None, 1)[1]), no, t))
+            events.append(("load", set(), no, t))
+            continue
         if in_asm and t.startswith("s_waitcnt") and "vmcnt" in t:
             n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
             events.append(("wait", n, no, t))
