@@ -6,6 +6,8 @@
 //   bce_metrics     : BCE-with-logits (sum reduction), d(loss)/d(logit), IoU / accuracy counts
 //   adam            : flat fused Adam (torch.optim.Adam semantics, amsgrad off)
 //   pack / unpack   : OIHW fp32 master weights <-> K-chunked compute layout [chunk][Npad][BK]
+#include <type_traits>
+
 #include "common.h"
 #include "gather.h"
 #include "pointwise.h"
@@ -230,9 +232,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
   const T* xp = (const T*)a.xpool;
   T* gy0 = (T*)a.gy0;
   if (rl < rpb) {
-    for (int p = blockIdx.x * rpb + rl; p < npix; p += gridDim.x * rpb) {
-      int b, y, x;
-      row_to_byx(p, a.H0, a.W0, b, y, x);
+    // (b, y, x) of the thread's pixel walk forward by the decomposed stride: two divisions per pixel were a sixth of the loop's instructions
+    const int stride = gridDim.x * rpb;
+    int sb, sy, sx;
+    row_to_byx(stride, a.H0, a.W0, sb, sy, sx);
+    int b, y, x;
+    row_to_byx(blockIdx.x * rpb + rl, a.H0, a.W0, b, y, x);
+    for (int p = blockIdx.x * rpb + rl; p < npix; p += stride) {
       float g[SLOT];
 #pragma unroll
       for (int i = 0; i < SLOT; ++i) g[i] = 0.f;
@@ -259,12 +265,30 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
       const V y0v = *(const V*)(y0 + (size_t)p * a.ld0 + c);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+        if constexpr (std::is_same<T, f16>::value) {
+          // f16: the effective gradient g + q + r x of a window on the packed halves (v_fma_mix_f32: two instructions per element; the lo parts
+          // of q, r are far below the storage rounding, as in gather.h eff_grad_slot)
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 gi = __builtin_bit_cast(u32x4, wg[w]), xi = __builtin_bit_cast(u32x4, wx_[w]);
+          const float one = 1.f;
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            float t0, t1, v0, v1;
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(xi[pr]), "v"(rr[2 * pr]), "v"(q[2 * pr]));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(xi[pr]), "v"(rr[2 * pr + 1]), "v"(q[2 * pr + 1]));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(v0) : "v"(gi[pr]), "v"(one), "v"(t0));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(v1) : "v"(gi[pr]), "v"(one), "v"(t1));
+            if (wok[w] && (int)((wam[w] >> (16 * pr)) & 0xff) == wk[w]) g[2 * pr] += v0;
+            if (wok[w] && (int)((wam[w] >> (16 * pr + 8)) & 0xff) == wk[w]) g[2 * pr + 1] += v1;
+          }
+        } else {
         float gf[SLOT], xf[SLOT];
         vec_to_f32<T>(wg[w], gf);
         vec_to_f32<T>(wx_[w], xf);
 #pragma unroll
         for (int i = 0; i < SLOT; ++i)
           if (wok[w] && (int)((wam[w] >> (8 * i)) & 0xff) == wk[w]) g[i] += (gf[i] + fmaf(rr[i], xf[i], q[i])) + fmaf(rlo[i], xf[i], qlo[i]);
+        }
       }
       float yf[SLOT], o[SLOT];
       vec_to_f32<T>(y0v, yf);
@@ -281,6 +305,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxpoolBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < SLOT; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; f1[i] = 0.f; f2[i] = 0.f; }
       }
+      x += sx; if (x >= a.W0) { x -= a.W0; ++y; }
+      y += sy; if (y >= a.H0) { y -= a.H0; ++b; }
+      b += sb;
     }
 #pragma unroll
     for (int i = 0; i < SLOT; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; }
