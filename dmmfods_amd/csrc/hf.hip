@@ -18,9 +18,12 @@
 //   * the epilogue is wave-local (a wave stages, reads back and stores its own 64 x 32 tile: no barrier), the BatchNorm sums of the
 //     stored values stay in an fp64 register for the whole walk (one round of atomics per workgroup).
 // K order = conv3.hip's (tap, chunk; then the raw taps): the results are bit-equal to conv3.hip's.
-// (Version 1 of this file - weights resident in LDS, an item as two K stretches over 64-channel half images, loads two items ahead -
-// ran at 0.93 ms and is in the history; this form 0.92: neither the LDS reads nor the loads' flight time are what an item's 3 us are
-// made of - profiles/r04/ablations.txt section 15.)
+// Measured (C2: 19200 tiles x 4 phases, 2 GB): conv3.hip 1.52-1.64 ms, this file 0.85.  Its -DHF_DBG ablations (profiles/r04/ablations.txt
+// section 15): the 76 MFMAs of an item cost 0.05 ms, the matrix waves' epilogue 0.3, the loader side alone 0.56 - on every SIMD one loader
+// wave and one matrix wave share the vector issue, and the matrix wave runs its K stretch and its epilogue one after the other.  Two
+// other forms were built and measured: version 1 (weights resident in LDS, an item as two K stretches over 64-channel half images, loads
+// two items ahead: 0.93 ms, in the history) and the epilogue handed to the loaders (stores in the loaders' in-order vmcnt queue make every
+// wait for a set of loads wait for the L2's write acknowledgements as well: 1.51 ms).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
