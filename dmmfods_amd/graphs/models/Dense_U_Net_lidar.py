@@ -101,8 +101,11 @@ class _Plan:
         return bool((self._raw[:g] == 0xA5).all()) and bool((self._raw[g + self.workspace.numel():] == 0xA5).all())
 
     def __del__(self):
+        # (not while the interpreter shuts down: the HIP runtime may already be gone by then - destroying the plan's streams and events
+        # behind it is a segmentation fault waiting for the right finalisation order; the process's exit frees everything anyway)
         try:
-            if self.handle:
+            import sys
+            if self.handle and not sys.is_finalizing():
                 _lib.lib().dmm_plan_destroy(self.handle)
                 self.handle = None
         except Exception:
