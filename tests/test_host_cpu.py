@@ -185,6 +185,34 @@ def test_plan_flops_match_survey(lib):
         L.dmm_plan_destroy(h)
 
 
+def test_plan_sizing_is_deterministic_and_independent_of_schedule_switches(lib, monkeypatch):
+    """dmm_plan_create needs no GPU and sizes the workspace in a dry pass that the bound pass must repeat byte for byte.  Round 4 added
+    tables whose size depends on what the plan decides (pack / unpack tile lists, the early / late pack cut, the interleaved encoders'
+    launch order): two plans of one description must agree, and the A/B switches that only change the ORDER of launches must not change
+    the size - a plan sized with one setting and bound with another would overrun its tables."""
+    L = lib.lib()
+
+    def size(cbb, s2, blocks, dtype):
+        d = lib.ModelDesc(growth_rate=32, num_blocks=4, num_init_features=64, bn_size=4, num_classes=3, concat_before_block_num=cbb,
+                          stream_1_in_channels=3, stream_2_in_channels=s2, batch=2, height=256, width=384, dtype=dtype, loss_scale=1.0,
+                          bn_momentum=0.1, bn_eps=1e-5, iou_threshold=0.7, use_mfma=1)
+        for i, v in enumerate(blocks):
+            d.block_config[i] = v
+        h = C.c_void_p()
+        lib.check(L.dmm_plan_create(C.byref(d), C.byref(h)))
+        n = L.dmm_plan_workspace_bytes(h)
+        L.dmm_plan_destroy(h)
+        return n
+
+    for cfg in ((1, 3, (6, 12, 24, 16), 1), (3, 3, (6, 12, 24, 16), 1), (3, 3, (6, 12, 48, 32), 2), (1, 0, (6, 12, 24, 16), 0)):
+        base = size(*cfg)
+        assert base > 0 and size(*cfg) == base
+        for knob in ("DMM_NO_S2_INTERLEAVE", "DMM_NO_CVP_MERGE", "DMM_NO_C3_MERGE", "DMM_NO_WGP_MERGE"):
+            monkeypatch.setenv(knob, "1")
+            assert size(*cfg) == base, (cfg, knob)
+            monkeypatch.delenv(knob)
+
+
 def test_config_fields_match_reference():
     from dmmfods_amd.utils.Dense_U_Net_lidar_helper import create_config, get_config
     cfg = get_config("/tmp/x")
