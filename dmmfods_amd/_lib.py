@@ -63,7 +63,7 @@ def lib():
     L.dmm_set_option.argtypes = [C.c_char_p, C.c_int]
     L.dmm_plan_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dmm_plan_destroy.argtypes = [vp]
-    L.dmm_plan_destroy.restype = None
+    L.dmm_plan_destroy.restype = C.c_int
     L.dmm_plan_num_tensors.argtypes = [vp]
     L.dmm_plan_tensor_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i32),
                                        C.POINTER(i64 * 4), C.POINTER(i64)]

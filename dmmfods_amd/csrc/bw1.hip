@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bw1_kernel(const Bw1Args g) {
   }
 }
 
-static bool g_bw1 = getenv("DMM_NO_BW1") == nullptr;
+static bool g_bw1 = !lab_flag("DMM_NO_BW1");
 void bw1_set_enabled(bool on) { g_bw1 = on; }
 bool bw1_enabled() { return g_bw1; }
 
@@ -448,7 +448,7 @@ Bw1Geom bw1_geometry(const ConvArgs& a) {
   // dmm_plan_workspace_bytes never touch the HIP runtime), and a launch must split exactly as the plan reserved.  The split is laid
   // out for the 256 compute units of the MI355X this library is written for.
   constexpr int cus = DESIGN_CUS;
-  static const int per_cu = getenv("DMM_BW1_PER_CU") ? atoi(getenv("DMM_BW1_PER_CU")) : 2;
+  static const int per_cu = lab_int("DMM_BW1_PER_CU", 2);
   // every workgroup ends with 64 KB of weight gradient to hand over and a tile is ~2 us of work: at least 4 tiles per workgroup
   int nsplit = std::max(1, (per_cu * cus + q.nct - 1) / q.nct);
   nsplit = std::min(nsplit, std::max(1, q.ntiles / 4));
@@ -460,7 +460,7 @@ Bw1Geom bw1_geometry(const ConvArgs& a) {
   return q;
 }
 
-static bool g_bw1_part = getenv("DMM_NO_BW1_PART") == nullptr;
+static bool g_bw1_part = !lab_flag("DMM_NO_BW1_PART");
 
 static bool bw1_uses_part(const Bw1Args& g, const Bw1Geom& q) {
   return g_bw1_part && g.part != nullptr && q.nsplit * q.nct <= g.part_slots && q.nsplit > 1;

@@ -6,7 +6,9 @@
 #include <cstring>
 #include <stdexcept>
 #include <chrono>
+#include <mutex>
 #include <string>
+#include <unistd.h>
 
 #include "plan.h"
 
@@ -30,6 +32,79 @@ static bool g_overlap_wgrad = getenv("DMM_NO_OVERLAP") == nullptr;
 static int g_graph = getenv("DMM_GRAPH") ? std::max(1, atoi(getenv("DMM_GRAPH"))) : 0;  // off by default: see launch_list (1: both lists, 2: the forward list only)
 static unsigned long long g_option_epoch = 1;  // bumped by every dmm_set_option: captured graphs have the options of their time baked in
 static int g_bucket_mb = getenv("DMM_GRAD_BUCKET_MB") ? atoi(getenv("DMM_GRAD_BUCKET_MB")) : 25;
+
+// ------------------------------------------------------------------------------------------------ streams and events of the process
+// One pool per device, created on first use and NEVER torn down: the three helper streams (side: weight gradients, backward leaves,
+// the second encoder; pack: the late layers' weight pack; capture: hipGraph capture) live as long as the process, events go back
+// to free lists when a plan is destroyed.  Round 4's teardown destroyed two low-priority streams and ~200 events per plan, ~350 plans
+// per test process, without synchronising anything - and the driver's GPU suite died of a segmentation fault raised on a runtime
+// thread (no Python thread state: faulthandler marked no thread "Current") while the main thread was inside dmm_plan_destroy.  The
+// last user of a priority level's hardware queue going away is a queue destruction inside the runtime; a plan has no business causing
+// one.  Nothing here is destroyed at exit either (no static destructor may touch a runtime that is unloading): the pointers leak by design.
+namespace {
+struct DevicePool {
+  std::mutex mu;
+  hipStream_t side = nullptr, pack = nullptr, capture = nullptr;
+  std::vector<hipEvent_t> free_plain, free_timing;   // hipEventDisableTiming / timing events handed back by destroyed plans
+  long events_made = 0;
+};
+constexpr int MAX_DEVICES = 64;
+DevicePool* g_pools[MAX_DEVICES] = {};
+std::mutex g_pools_mu;
+
+DevicePool* pool_of(int device) {
+  if (device < 0 || device >= MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> l(g_pools_mu);
+  if (g_pools[device] == nullptr) g_pools[device] = new DevicePool();
+  return g_pools[device];
+}
+// the helper streams of the CURRENT device's pool (created on first use)
+hipError_t pool_streams(DevicePool* dp, bool want_capture) {
+  std::lock_guard<std::mutex> l(dp->mu);
+  if (dp->side == nullptr) {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e != hipSuccess) return e;
+    // lowest priority: the data-gradient chain on the caller's stream is the longer dependency chain (mid / high measured in round 2:
+    // 33.6 / 33.8 / 33.9 ms; confining the stream to a CU mask in round 4: 41-57 ms instead of 28)
+    hipStream_t s = nullptr, k = nullptr;
+    if ((e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&k, hipStreamNonBlocking, lo)) != hipSuccess) return e;   // (s leaks: the process is in trouble anyway)
+    dp->side = s; dp->pack = k;
+  }
+  if (want_capture && dp->capture == nullptr) {
+    hipStream_t c = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    dp->capture = c;
+  }
+  return hipSuccess;
+}
+hipEvent_t pool_event(DevicePool* dp, bool timing) {
+  std::lock_guard<std::mutex> l(dp->mu);
+  auto& fl = timing ? dp->free_timing : dp->free_plain;
+  if (!fl.empty()) { hipEvent_t e = fl.back(); fl.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  const hipError_t rc = timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (rc != hipSuccess) return nullptr;
+  ++dp->events_made;
+  return e;
+}
+void pool_return(DevicePool* dp, std::vector<void*>& evs, bool timing) {
+  std::lock_guard<std::mutex> l(dp->mu);
+  auto& fl = timing ? dp->free_timing : dp->free_plain;
+  for (void* e : evs) if (e) fl.push_back((hipEvent_t)e);
+  evs.clear();
+}
+// DMM_TRACE_DESTROY=1: one line per teardown step, written straight to fd 2 (no buffering: the line in front of a fault survives it)
+void trace_destroy(const char* what) {
+  static const bool on = getenv("DMM_TRACE_DESTROY") != nullptr;
+  if (!on) return;
+  char buf[160];
+  const int n = snprintf(buf, sizeof(buf), "[dmm] destroy: %s\n", what);
+  if (n > 0) { ssize_t w = write(2, buf, (size_t)std::min<int>(n, (int)sizeof(buf) - 1)); (void)w; }
+}
+}  // namespace
 
 extern "C" {
 
@@ -67,6 +142,7 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   if (!(desc->loss_scale > 0)) return fail(DMM_ERR_INVALID, "loss_scale must be > 0");
   dmm_plan* p = new dmm_plan();
   p->desc = *desc;
+  p->sw = PlanSwitches::from_environment();   // the only place a plan's switches are read
   p->bucket_bytes = (size_t)g_bucket_mb << 20;
   try {
     plan_build_tables(p);
@@ -81,16 +157,51 @@ int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out) {
   return DMM_OK;
 }
 
-void dmm_plan_destroy(dmm_plan* plan) {
-  if (!plan) return;
-  for (void* e : plan->fork_events) hipEventDestroy((hipEvent_t)e);
-  for (void* e : plan->bucket_events) hipEventDestroy((hipEvent_t)e);
-  for (void* e : plan->join_events) hipEventDestroy((hipEvent_t)e);
-  for (void* s2 : plan->side_streams) hipStreamDestroy((hipStream_t)s2);
-  for (auto& gc : plan->graphs)
-    for (auto& e : gc.entries) hipGraphExecDestroy((hipGraphExec_t)e.exec);
-  if (plan->capture_stream) hipStreamDestroy((hipStream_t)plan->capture_stream);
+// Teardown contract (tests/test_host_cpu.py drives it under AddressSanitizer against a fake runtime that counts violations):
+//   * every helper stream this plan has launched on is synchronised first - when the call returns nothing the library enqueued
+//     outside the caller's own stream still reads the workspace or the arenas, so the caller may free them (what it enqueued on
+//     the stream it passed in is the caller's to order, as with any stream-ordered allocator);
+//   * no stream is destroyed (they belong to the process pool), events go back to the pool, a graph is destroyed behind its stream's
+//     synchronisation; every HIP return code is looked at, the first failure is reported (DMM_ERR_HIP) and the teardown still completes;
+//   * destroying NULL is DMM_OK; a handle must not be used after the call, whatever it returned.
+int dmm_plan_destroy(dmm_plan* plan) {
+  if (!plan) return DMM_OK;
+  trace_destroy("begin");
+  std::string first_err;
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && first_err.empty()) first_err = std::string(what) + ": " + hipGetErrorString(e);
+  };
+  DevicePool* dp = plan->device >= 0 ? pool_of(plan->device) : nullptr;
+  if (dp != nullptr) {
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != plan->device && hipSetDevice(plan->device) == hipSuccess;
+    if (plan->used_side) {
+      trace_destroy("synchronise the side stream");
+      note(hipStreamSynchronize(dp->side), "hipStreamSynchronize(side stream)");
+      trace_destroy("synchronise the pack stream");
+      note(hipStreamSynchronize(dp->pack), "hipStreamSynchronize(pack stream)");
+    }
+    if (plan->used_capture && dp->capture) {
+      trace_destroy("synchronise the capture stream");
+      note(hipStreamSynchronize(dp->capture), "hipStreamSynchronize(capture stream)");
+    }
+    trace_destroy("graphs");
+    for (auto& gc : plan->graphs) {
+      for (auto& e : gc.entries) note(hipGraphExecDestroy((hipGraphExec_t)e.exec), "hipGraphExecDestroy");
+      gc.entries.clear();
+    }
+    trace_destroy("events back to the pool");
+    pool_return(dp, plan->fork_events, false);
+    pool_return(dp, plan->join_events, false);
+    pool_return(dp, plan->bucket_events, false);
+    for (auto& which : plan->prof_events)
+      for (auto& pass : which) pool_return(dp, pass, true);
+    if (switched) (void)hipSetDevice(cur);
+  }
+  trace_destroy("delete");
   delete plan;
+  trace_destroy("done");
+  return first_err.empty() ? DMM_OK : fail(DMM_ERR_HIP, "dmm_plan_destroy: " + first_err);
 }
 
 int dmm_plan_num_tensors(const dmm_plan* plan) { return plan ? (int)plan->tensors.size() : 0; }
@@ -118,12 +229,20 @@ int dmm_plan_bind(dmm_plan* plan, void* workspace, size_t workspace_bytes, float
   if ((uintptr_t)workspace % 256) return fail(DMM_ERR_INVALID, "workspace must be 256-byte aligned");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMM_ERR_NO_DEVICE, "no HIP device");
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (plan->device >= 0 && plan->device != dev) return fail(DMM_ERR_STATE, "the plan is bound to another device");
+  if (dev >= MAX_DEVICES) return fail(DMM_ERR_INVALID, "device index out of range");
+  plan->device = dev;
   plan->params = params;
   plan->grads = grads;
   plan->buffers = buffers;
   plan->graphs[0].epoch = plan->graphs[1].epoch = 0;  // captured graphs hold the old pointers
+  plan->bound = false;
   try {
     plan_bind(plan, workspace);
+  } catch (const dmm::plan_sizing_error& e) {
+    return fail(DMM_ERR_STATE, e.what());
   } catch (const std::exception& e) {
     return fail(DMM_ERR_INVALID, e.what());
   }
@@ -146,9 +265,10 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     if ((int)sets.size() <= pass) sets.resize(pass + 1);
     evs = &sets[pass];
     const size_t need = 2 * (ops.size() + ev_offset);
+    DevicePool* pdp = pool_of(p->device);
     while (evs->size() < need) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+      hipEvent_t e = pdp ? pool_event(pdp, true) : nullptr;
+      if (e == nullptr) return fail(DMM_ERR_HIP, "hipEventCreate failed");
       evs->push_back((void*)e);
     }
   }
@@ -163,25 +283,19 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   constexpr int nside = 1;  // 2 and 3 side streams measured: 0.3 / 0.6 ms slower; and the leaf chains need one FIFO
   size_t nfork = 0;
   bool forked = false;
+  DevicePool* dp = pool_of(p->device);
+  hipStream_t side_st = nullptr, pack_st = nullptr;
   if (overlap) {
-    while ((int)p->side_streams.size() < nside + 1) {  // [nside]: the pack stream
-      int lo = 0, hi = 0;
-      hipDeviceGetStreamPriorityRange(&lo, &hi);
-      hipStream_t s2;
-      // DMM_SIDE_PRIO = hi | mid: experiment knob (default: lowest priority, the data-gradient chain is the longer dependency chain)
-      const char* sp = getenv("DMM_SIDE_PRIO");
-      const int prio = sp && sp[0] == 'h' ? hi : (sp && sp[0] == 'm' ? (lo + hi) / 2 : lo);
-      // (round 4: confining this stream to 32-128 CUs with hipExtStreamCreateWithCUMask made the step 41-57 ms instead of 28 - even the
-      // one-stream profiling pass slowed down; profiles/r04/ablations.txt)
-      const hipError_t se = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio);
-      if (se != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
-      hipEvent_t je;
-      if (hipEventCreateWithFlags(&je, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
-      p->side_streams.push_back((void*)s2);
+    if (dp == nullptr || pool_streams(dp, false) != hipSuccess) return fail(DMM_ERR_HIP, "side stream");
+    side_st = dp->side; pack_st = dp->pack;
+    while ((int)p->join_events.size() < nside + 1) {  // [nside]: the pack stream's
+      hipEvent_t je = pool_event(dp, false);
+      if (je == nullptr) return fail(DMM_ERR_HIP, "hipEventCreate failed");
       p->join_events.push_back((void*)je);
     }
+    p->used_side = true;
   }
-  // The pack stream (side_streams[1]): the launch that packs the weights of the LATE layers (leaf == 2) runs there beside the first
+  // The pack stream: the launch that packs the weights of the LATE layers (leaf == 2) runs there beside the first
   // layers of the forward pass; OP_JOIN with epi == 1 in front of the first late layer makes the main stream wait for it.
   bool pack_pending = false;
   auto join_pack = [&]() {
@@ -193,7 +307,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   auto join_side = [&]() {
     if (forked) {
       for (int k = 0; k < nside; ++k) {
-        hipEventRecord((hipEvent_t)p->join_events[k], (hipStream_t)p->side_streams[k]);
+        hipEventRecord((hipEvent_t)p->join_events[k], side_st);
         hipStreamWaitEvent(st, (hipEvent_t)p->join_events[k], 0);
       }
       forked = false;
@@ -201,7 +315,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
   };
   auto join = [&]() { join_side(); join_pack(); };
   // DMM_HOST_PROF=1: host time of the enqueue calls by op kind, printed when a list has run 20 times (tools/host_bound.py)
-  static const bool host_prof = getenv("DMM_HOST_PROF") != nullptr;
+  static const bool host_prof = lab_flag("DMM_HOST_PROF");
   static double hp_launch[32] = {0}, hp_fork[32] = {0};
   static long hp_n[32] = {0}, hp_lists = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -212,18 +326,19 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     double hp_t1 = hp_t0;
     // side-stream launches: weight gradients and the leaves of the backward graph (stem, raw-input branches)
     hipStream_t lst = st;
-    if (overlap && o.leaf == 3) {
+    if (overlap && o.leaf == 3 && forked) {
       // a launch that continues a chain on the side stream (the second stream's encoder): everything it reads was produced by the
-      // launch in front of it on that stream, or before the chain's first launch (which forked from the main stream)
-      lst = (hipStream_t)p->side_streams[0];
-      forked = true;
+      // launch in front of it on that stream, or before the chain's first launch (which forked from the main stream).  Only while
+      // the side stream is forked in THIS call: a range that starts mid-chain, or a join inside the chain, makes the next launch
+      // of the chain fork again like any leaf.
+      lst = side_st;
     } else if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
       if (nfork >= p->fork_events.size()) {
-        hipEvent_t fe;
-        if (hipEventCreateWithFlags(&fe, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+        hipEvent_t fe = pool_event(dp, false);
+        if (fe == nullptr) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
         p->fork_events.push_back((void*)fe);
       }
-      lst = (hipStream_t)p->side_streams[o.leaf == 2 ? nside : 0];
+      lst = o.leaf == 2 ? pack_st : side_st;
       hipEvent_t fe = (hipEvent_t)p->fork_events[nfork++];
       hipEventRecord(fe, st);
       hipStreamWaitEvent(lst, fe, 0);
@@ -258,8 +373,8 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
     if (pack_pending && o.leaf == 2) hipEventRecord((hipEvent_t)p->join_events[nside], lst);
     if (o.signal >= 0 && !capturing) {  // a gradient bucket is final on this stream from here on
       while ((int)p->bucket_events.size() <= o.signal) {
-        hipEvent_t be;
-        if (hipEventCreateWithFlags(&be, hipEventDisableTiming) != hipSuccess) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
+        hipEvent_t be = dp ? pool_event(dp, false) : nullptr;
+        if (be == nullptr) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
         p->bucket_events.push_back((void*)be);
       }
       hipEventRecord((hipEvent_t)p->bucket_events[o.signal], lst);
@@ -282,8 +397,9 @@ static int record_bucket_events(dmm_plan* p, const std::vector<Op>& ops, hipStre
   for (const Op& o : ops) {
     if (o.signal < 0) continue;
     while ((int)p->bucket_events.size() <= o.signal) {
-      hipEvent_t be;
-      if (hipEventCreateWithFlags(&be, hipEventDisableTiming) != hipSuccess) return fail(DMM_ERR_HIP, "hipEventCreate failed");
+      DevicePool* dp = pool_of(p->device);
+      hipEvent_t be = dp ? pool_event(dp, false) : nullptr;
+      if (be == nullptr) return fail(DMM_ERR_HIP, "hipEventCreate failed");
       p->bucket_events.push_back((void*)be);
     }
     HIPCHK(hipEventRecord((hipEvent_t)p->bucket_events[o.signal], st));
@@ -315,12 +431,10 @@ static int launch_list(dmm_plan* p, int which, std::vector<Op>& ops, size_t seg_
   const bool want = g_graph && !(g_graph == 2 && which == 1) && !p->graph_failed && !profiling && !(which == 1 && p->dp_used) && seg_end > seg_begin + 8;
   if (!want) return run_ops(p, ops, st, which);
   if (gc.entries.empty() && gc.nseen > 0) {  // the second run of the list: capture the segment
-    if (p->capture_stream == nullptr) {
-      hipStream_t cs;
-      if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail(DMM_ERR_HIP, "capture stream");
-      p->capture_stream = (void*)cs;
-    }
-    hipStream_t cs = (hipStream_t)p->capture_stream;
+    DevicePool* dp = pool_of(p->device);
+    if (dp == nullptr || pool_streams(dp, true) != hipSuccess) return fail(DMM_ERR_HIP, "capture stream");
+    hipStream_t cs = dp->capture;
+    p->used_capture = true;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -332,7 +446,7 @@ static int launch_list(dmm_plan* p, int which, std::vector<Op>& ops, size_t seg_
       if (graph) hipGraphDestroy(graph);
     }
     gc.captures++;
-    static const bool gtrace = getenv("DMM_GRAPH_TRACE") != nullptr;
+    static const bool gtrace = lab_flag("DMM_GRAPH_TRACE");
     if (gtrace) fprintf(stderr, "[dmm] graph capture of list %d, launches [%zu, %zu): %s\n", which, seg_begin, seg_end, ok ? "ok" : "FAILED");
     if (!ok) {
       (void)hipGetLastError();

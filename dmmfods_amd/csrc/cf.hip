@@ -250,7 +250,7 @@ static hipError_t launch_cf_t(const CfArgs& g, int nwg, hipStream_t st) {
 // output channels, whole 8 x 16 tiles and at least DMM_CF_MIN_TILES of them (default: eight per CU - measured: 4800 tiles 87 -> 70 us, 1200 tiles 29 -> 30 us), 16-bit storage.
 // hipErrorNotSupported otherwise (conv3.hip takes the launch then).
 hipError_t launch_cf(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
-  if (!family_on(getenv("DMM_NO_CF") == nullptr, IMPL_CF) || dtype == DT_F32 || epi != EPI_STORE || a.nphase != 0 || a.nseg != 1 || a.pool2) return hipErrorNotSupported;
+  if (!family_on(!lab_flag("DMM_NO_CF"), IMPL_CF) || dtype == DT_F32 || epi != EPI_STORE || a.nphase != 0 || a.nseg != 1 || a.pool2) return hipErrorNotSupported;
   const Seg& u = a.seg[0];
   if (u.mode != G_PLAIN || u.istride != 1 || u.C != 128 || u.Cpad != 128 || u.Hs != a.Ho || u.Ws != a.Wo || u.scale == nullptr || u.ntaps != CF_NTAP) return hipErrorNotSupported;
   if (a.N != CF_BN || a.Npad != CF_BN || a.out == nullptr || a.ostride != 1 || a.Hout != a.Ho || a.Wout != a.Wo) return hipErrorNotSupported;
@@ -272,7 +272,7 @@ hipError_t launch_cf(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   g.tiles_y = a.Ho / CF_TH;
   g.tiles_x = a.Wo / CF_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
-  static const int min_tiles = getenv("DMM_CF_MIN_TILES") ? atoi(getenv("DMM_CF_MIN_TILES")) : 8 * DESIGN_CUS;
+  static const int min_tiles = lab_int("DMM_CF_MIN_TILES", 8 * DESIGN_CUS);
   if (g.ntiles < min_tiles) return hipErrorNotSupported;   // a few tiles per CU: 72 KB of weights per workgroup do not pay
   if (g_ctl.dry) return hipSuccess;
   g.c = a;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace dmm {
 
@@ -158,6 +159,7 @@ enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IM
 struct LaunchCtl {
   bool dry = false;      // walk the eligibility tests, launch nothing
   int impl = IMPL_AUTO;  // the one family allowed to take the launch (IMPL_AUTO: every enabled family, in dispatch order)
+  unsigned deny = 0;     // 1 << family for families a plan under construction must not pick (PlanSwitches, plan.h)
 };
 extern thread_local LaunchCtl g_ctl;  // (defined in pointwise.hip)
 // The family that took the calling thread's most recent convolution / weight-gradient / fused-backward launch (dmm_last_impl):
@@ -165,7 +167,24 @@ extern thread_local LaunchCtl g_ctl;  // (defined in pointwise.hip)
 extern thread_local int g_last_impl;
 extern thread_local unsigned g_impl_mask;  // 1 << family for every launch since the mask was last reset (dmm_impl_mask)
 inline void note_impl(int impl) { g_last_impl = impl; g_impl_mask |= 1u << impl; }
-inline bool family_on(bool enabled, int family) { return g_ctl.impl == IMPL_AUTO ? enabled : g_ctl.impl == family; }
+inline bool family_on(bool enabled, int family) { return g_ctl.impl == IMPL_AUTO ? (enabled && !((g_ctl.deny >> family) & 1u)) : g_ctl.impl == family; }
+
+// Lab knobs: launch-geometry and ablation switches whose experiments are recorded (profiles/*/ablations.txt).  The
+// shipped library fixes them at their defaults - no getenv, nothing an embedding process can trip over; a lab build
+// (-DDMM_LAB=1: tools/build_variant.sh, loaded through DMM_LIB_PATH) reads them from the environment again, once per process.
+// The run-time switches that remain are listed in plan.h (PlanSwitches) and capi.cpp; each has a test.
+#ifndef DMM_LAB
+#define DMM_LAB 0
+#endif
+#if DMM_LAB
+inline int lab_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+inline bool lab_flag(const char* name) { return getenv(name) != nullptr; }
+inline const char* lab_str(const char* name) { return getenv(name); }
+#else
+inline constexpr int lab_int(const char*, int dflt) { return dflt; }
+inline constexpr bool lab_flag(const char*) { return false; }
+inline constexpr const char* lab_str(const char*) { return nullptr; }
+#endif
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ float to_f32(float v) { return v; }

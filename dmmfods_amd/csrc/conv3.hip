@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static bool g_conv3 = getenv("DMM_NO_CONV3") == nullptr;
+static bool g_conv3 = !lab_flag("DMM_NO_CONV3");
 void conv3_set_enabled(bool on) { g_conv3 = on; }
 
 
@@ -512,7 +512,7 @@ static hipError_t launch_c3(const Conv3Args& g, hipStream_t st) {
   // a launch with fewer tiles than that runs one tile per workgroup, as before
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const int rounds = getenv("DMM_C3_ROUNDS") ? atoi(getenv("DMM_C3_ROUNDS")) : 1;
+  static const int rounds = lab_int("DMM_C3_ROUNDS", 1);
   const int per_cu = std::min(4, (160 * 1024) / SM::bytes);
   int nwg = g.ntiles * (g.c.nphase > 0 ? g.c.nphase : 1);
   if (EPI == EPI_STORE && rounds > 0 && nwg > per_cu * cus * rounds) nwg = per_cu * cus * rounds / 8 * 8;
@@ -612,7 +612,7 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
   const int nt = a.Npad / 32;
-  static const bool trace = getenv("DMM_C3_TRACE") != nullptr;
+  static const bool trace = lab_flag("DMM_C3_TRACE");
   if (trace && !g_ctl.dry) fprintf(stderr, "conv3: epi %d pro %d cs %d span %d tspan %d tstr %d nt %d M %d\n", epi, pro, cs, span, tspan, tstr, nt, a.M);
   return dtype == DT_F16 ? launch_c3_type<f16>(g, epi, pro, cs, span, tspan, tstr, nt, st)
                          : launch_c3_type<bf16>(g, epi, pro, cs, span, tspan, tstr, nt, st);

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   }
 }
 
-static bool g_cvp = getenv("DMM_NO_CVP") == nullptr;
+static bool g_cvp = !lab_flag("DMM_NO_CVP");
 void cvp_set_enabled(bool on) { g_cvp = on; }
 
 

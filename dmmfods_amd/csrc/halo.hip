@@ -460,7 +460,7 @@ hipError_t launch_halo_f32(const HaloArgs& h, int epi, hipStream_t st);  // halo
 // Returns hipErrorNotSupported when the layer is not eligible.
 hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   HaloArgs h;
-  static const bool no_halo = getenv("DMM_NO_HALO") != nullptr;
+  static const bool no_halo = lab_flag("DMM_NO_HALO");
   if (!family_on(!no_halo, IMPL_HALO) || dtype == DT_BF16) return hipErrorNotSupported;  // bf16 layers take the generic / thin kernels
   if (a.pool2 || !halo_plan(a, dtype, epi, h)) return hipErrorNotSupported;
   if (epi != EPI_BNBWD && a.seg[0].q != nullptr) return hipErrorNotSupported;
@@ -469,7 +469,7 @@ hipError_t launch_halo(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   // Measured on MI355X (C2, b4): with one wave per SIMD the tile phases of this kernel do not overlap yet, so it only beats
   // the generic kernel (2-3 workgroups per CU) where the tap count is large: the 5x5 logits conv (7.9 -> 4.3 ms).  The
   // other eligible layers stay on igemm unless DMM_HALO_ALL is set.
-  static const bool all = getenv("DMM_HALO_ALL") != nullptr;
+  static const bool all = lab_flag("DMM_HALO_ALL");
   if (!all && epi != EPI_LOGITS) return hipErrorNotSupported;
   if (g_ctl.dry) return (epi == EPI_STORE && (h.c.Npad == 64 || h.c.Npad == 32)) || (epi == EPI_LOGITS && h.c.Npad == 32) ||
                         (epi == EPI_BNBWD && (h.c.Npad == 128 || h.c.Npad == 64 || h.c.Npad == 32)) ? hipSuccess : hipErrorNotSupported;

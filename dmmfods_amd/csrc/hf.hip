@@ -371,8 +371,8 @@ static bool hf_tap_box(const short* taps, int ntaps, int want_span, int& dymin, 
 // half-resolution segment with 2x2 taps per phase, an 8-channel raw segment with 3x3 taps at stride 2, 64 output channels stored at
 // stride 2, whole 8 x 16 tiles, 16-bit storage.  hipErrorNotSupported otherwise (conv3.hip takes the launch then).
 hipError_t launch_hf(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
-  // (DMM_NO_HF is read per call: the plan decides the family when it is built, and the tests switch it between plans)
-  if (!family_on(getenv("DMM_NO_HF") == nullptr, IMPL_HF) || dtype == DT_F32 || epi != EPI_STORE || a.nphase != 4 || a.nseg != 2 || a.pool2) return hipErrorNotSupported;
+  // (DMM_NO_HF: read when a plan is created - PlanSwitches::no_hf, plan.h - and applied through g_ctl.deny while it is built)
+  if (!family_on(true, IMPL_HF) || dtype == DT_F32 || epi != EPI_STORE || a.nphase != 4 || a.nseg != 2 || a.pool2) return hipErrorNotSupported;
   const Seg& u = a.seg[0];
   const Seg& t = a.seg[1];
   if (u.mode != G_PLAIN || u.istride != 1 || u.C != 128 || u.Cpad != 128 || u.Hs != a.Ho || u.Ws != a.Wo || u.scale == nullptr || u.ntaps != 4) return hipErrorNotSupported;
@@ -394,7 +394,7 @@ hipError_t launch_hf(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   g.tiles_x = a.Wo / HF_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
   // one workgroup per CU (152 KB of LDS), in whole groups of 4 phases x 8 XCDs; launches with fewer tile groups than that: one item each
-  static const int cus = getenv("DMM_HF_WGS") ? atoi(getenv("DMM_HF_WGS")) : DESIGN_CUS;
+  static const int cus = lab_int("DMM_HF_WGS", DESIGN_CUS);
   int nwg = std::max(32, cus / 32 * 32);
   const int need = (g.ntiles + 7) / 8 * 32;   // ntiles groups rounded up to whole XCD rows
   nwg = std::min(nwg, need);

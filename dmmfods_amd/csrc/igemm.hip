@@ -728,7 +728,7 @@ static hipError_t launch_bn_ks(const ConvArgs& a, bool mfma, hipStream_t st) {
 template <typename T, int BN, int EPI>
 static hipError_t launch_bn(const ConvArgs& a, bool mfma, hipStream_t st) {
   if constexpr (((IGEMM_FAT && sizeof(T) == 2 && BN == 128) || (IGEMM_FAT_F32 && sizeof(T) == 4 && BN == 32)) && EPI != EPI_LOGITS) {
-    static const int fat_wgs = getenv("DMM_FAT_WGS") ? atoi(getenv("DMM_FAT_WGS")) : (sizeof(T) == 4 ? 128 : 512);
+    static const int fat_wgs = lab_int("DMM_FAT_WGS", sizeof(T) == 4 ? 128 : 512);
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += a.seg[s].nchunks;
     const int wgs = ((a.M + BM - 1) / BM) * (a.Npad / BN);
@@ -750,7 +750,7 @@ static hipError_t launch_epi(const ConvArgs& a, bool mfma, hipStream_t st) {
   // fp32 storage is the opposite case (round 3, C1 = 1x256x384): a 48-workgroup launch with K = 1024 is 2048 v_mfma_f32_32x32x2_f32 of 64
   // cycles per wave - bound by the fp32 matrix rate of a fifth of the chip.  Narrower tiles spread the same MFMAs over more CUs:
   // 16.7 -> 11.9 ms/step at 128 workgroups or more.  Default: 256 for fp32, 0 for the 16-bit types.
-  static const int min_wgs = getenv("DMM_MIN_WGS") ? atoi(getenv("DMM_MIN_WGS")) : (sizeof(T) == 4 ? 256 : 0);
+  static const int min_wgs = lab_int("DMM_MIN_WGS", sizeof(T) == 4 ? 256 : 0);
   const int mtiles = (a.M + BM - 1) / BM;
   int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
   while (bn > 32 && mtiles * (a.Npad / bn) < min_wgs) bn >>= 1;

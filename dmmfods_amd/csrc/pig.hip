@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void pig_kernel(const PigArgs g) {
   }
 }
 
-static bool g_pig = getenv("DMM_NO_PIG") == nullptr;
+static bool g_pig = !lab_flag("DMM_NO_PIG");
 void pig_set_enabled(bool on) { g_pig = on; }
 
 // Takes a forward launch (EPI_STORE) of a plain 1x1 convolution behind BN+ReLU in a 16-bit storage type whose padded output width
@@ -264,7 +264,7 @@ hipError_t launch_pig(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   g.ntiles = a.Npad / PG_BN;
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const int per_cu = getenv("DMM_PIG_PER_CU") ? atoi(getenv("DMM_PIG_PER_CU")) : 2;
+  static const int per_cu = lab_int("DMM_PIG_PER_CU", 2);
   g.walkers = std::max(1, std::min(g.mtiles, (std::min(per_cu, fit) * cus) / g.ntiles));
   const int nwg = g.walkers * g.ntiles;
   auto kern = dtype == DT_F16 ? pig_kernel<f16> : pig_kernel<bf16>;

@@ -308,6 +308,7 @@ struct Builder {
   const int dtype, esz, SLOT, BK;
   const bool sizing;
   uint8_t *zbase, *zbbase, *wbase;
+  float *Pp, *Pg, *Pb;  // bases of the parameter / gradient / buffer arenas (see the constructor)
   Bump Z, ZB, W;  // Z: forward accumulators (BN statistics); ZB: backward accumulators (reductions, q/r, packed dW, metrics)
   std::map<std::string, const TensorInfo*> tmap;
   std::vector<Buf> bufs;
@@ -323,9 +324,19 @@ struct Builder {
   Builder(dmm_plan& p, bool sizing_, uint8_t* ws)
       : P(p), d(p.desc), g(p.desc), dtype(p.desc.dtype), esz((int)dtype_size(p.desc.dtype)), SLOT(16 / esz), BK(4 * (16 / esz)),
         sizing(sizing_) {
-    zbase = ws;
-    zbbase = sizing ? nullptr : ws + p.zero_bytes;
-    wbase = sizing ? nullptr : ws + p.zero_bytes + p.zero_bwd_bytes;
+    // The sizing pass (dmm_plan_create: no workspace, no arenas yet) walks the SAME code as the bound pass and must take the same
+    // decisions: several of them test a pointer for null (a buffer without gradient, a BatchNorm without statistics, a descriptor
+    // without a master gradient).  With null bases the FIRST allocation of every region and the tensor at arena offset 0 looked null
+    // in the sizing pass only (the tile count of the unpack table could then differ between the passes, and with it
+    // every later workspace offset).  So the sizing pass gets distinct, never dereferenced, non-null bases; plan_bind compares the
+    // bytes the bound pass took with the sized ones and refuses to bind on any difference.
+    auto fake = [](int k) { return (uint8_t*)(uintptr_t)((0x100ull + (uintptr_t)k) << 40); };
+    zbase = sizing ? fake(0) : ws;
+    zbbase = sizing ? fake(1) : ws + p.zero_bytes;
+    wbase = sizing ? fake(2) : ws + p.zero_bytes + p.zero_bwd_bytes;
+    Pp = sizing ? (float*)fake(3) : p.params;
+    Pg = sizing ? (float*)fake(4) : p.grads;
+    Pb = sizing ? (float*)fake(5) : p.buffers;
     for (auto& t : P.tensors) tmap[t.name] = &t;
   }
 
@@ -342,7 +353,7 @@ struct Builder {
 
   int new_buf(int B, int H, int W_, int cw, bool grad, bool stats, bool matz = false) {
     Buf b;
-    b.matz = matz && getenv("DMM_NO_MATZ") == nullptr;
+    b.matz = matz && !lab_flag("DMM_NO_MATZ");
     // Pixel pitch: power-of-two pitches make every workgroup hit the same HBM channels at the same time (all of them read
     // the same 64-byte column window of their rows as they walk K in step), so wide buffers get an odd multiple of 64 B.
     int ld = cw;
@@ -365,9 +376,9 @@ struct Builder {
     b.C = C;
     const TensorInfo &w = T(prefix + ".weight"), &bi = T(prefix + ".bias"), &rm = T(prefix + ".running_mean"),
                      &rv = T(prefix + ".running_var");
-    b.gamma = P.params + w.off; b.beta = P.params + bi.off;
-    b.dgamma = P.grads + w.off; b.dbeta = P.grads + bi.off;
-    b.rm = P.buffers + rm.off; b.rv = P.buffers + rv.off;
+    b.gamma = Pp + w.off; b.beta = Pp + bi.off;
+    b.dgamma = Pg + w.off; b.dbeta = Pg + bi.off;
+    b.rm = Pb + rm.off; b.rv = Pb + rv.off;
     const int cp = rup(C, 8) + 8;
     b.scale = wptr<float>(cp); b.shift = wptr<float>(cp); b.mean = wptr<float>(cp); b.invstd = wptr<float>(cp);
     b.red1 = zbptr<double>((size_t)cp * STAT_REPS); b.red2 = zbptr<double>((size_t)cp * STAT_REPS);  // replica stride = cp
@@ -386,7 +397,7 @@ struct Builder {
     PackDesc pd;
     memset(&pd, 0, sizeof(pd));
     const TensorInfo& w = T(c.wname);
-    pd.w = P.params + w.off;
+    pd.w = Pp + w.off;
     const long long RS = (long long)c.R * c.S;
     long long base_off = 0;
     if (!dgrad_seg) {
@@ -396,7 +407,7 @@ struct Builder {
       else { pd.sn = RS; pd.sk = (long long)c.N * RS; }
       for (int s = 0; s < c.nseg; ++s)
         fill_pack_seg(pd.seg[s], (s == 1 && taps1 && !taps1->empty()) ? *taps1 : taps, c.seg[s].Cw, c.seg[s].C, c.seg[s].koff, BK);
-      pd.gw = P.grads + w.off;
+      pd.gw = Pg + w.off;
       pd.shared_master = c.shared_master ? 1 : 0;
     } else {
       const SegRec& sr = c.seg[seg_index];
@@ -429,10 +440,10 @@ struct Builder {
   bool leaf_scope = false;  // ops emitted now feed only parameter gradients (stem / raw-input branches)
   float* wg3_part = nullptr;  // wg3.hip's slots, shared by every launch of the family
   bool wg3_part_taken = false;
-  const bool front_matz = getenv("DMM_NO_FRONT_MATZ") == nullptr;  // A/B knob
+  const bool front_matz = !lab_flag("DMM_NO_FRONT_MATZ");  // lab knob
   // which multi-consumer gradients are materialised (q + r*y applied once by applycorr) instead of corrected by every consumer's
   // prologue: 1 the decoder's conv_reduce outputs, 2 the last ConvTranspose's output, 4 refine0's output (A/B knob)
-  const int matz_mask = getenv("DMM_MATZ_MASK") ? atoi(getenv("DMM_MATZ_MASK")) : 7;
+  const int matz_mask = lab_int("DMM_MATZ_MASK", 7);
   // Deferred weight gradients (round 4).  The head's and the decoder's multi-tap weight gradients (wgp / wg5: 4 ms of work alone)
   // are the FIRST things backward can start on the weight-gradient stream - and they then run beside the head's and the decoder's
   // data gradients, the heaviest stretch of the main chain: measured with the launches skipped, they cost 3.2 ms of a 27.8 ms step,
@@ -585,7 +596,7 @@ struct Builder {
     }
     // Four phases of the two-segment head convolution, all on conv3.hip: ONE launch that walks (tile, phase) pairs - the four phases of
     // a tile run side by side on one XCD and the half-resolution input (0.8 GB at C2) comes from HBM once instead of four times.
-    if (c.phases.size() == 4 && c.nseg == 2 && ops->size() >= 4 && getenv("DMM_NO_C3_MERGE") == nullptr) {
+    if (c.phases.size() == 4 && c.nseg == 2 && ops->size() >= 4 && !P.sw.no_c3_merge) {
       const size_t first = ops->size() - 4;
       bool ok = true;
       for (size_t k = first; k < ops->size(); ++k) {
@@ -621,7 +632,7 @@ struct Builder {
     // The four parity phases of a ConvTranspose (1, 2, 2, 4 taps), all on cvp.hip: ONE launch.  A phase of the first decoder stage is 600
     // workgroups of 128 x 128 outputs for 512 slots on the chip (two per CU) - two rounds, the second 17 % full; 1200 in the second stage - three
     // rounds.  One launch deals the 2400 (4800) workgroups of all phases, the 4-tap phase first, and the slots stay full.
-    if (c.phases.size() == 4 && c.nseg == 1 && c.transposed && ops->size() >= 4 && getenv("DMM_NO_CVP_MERGE") == nullptr) {
+    if (c.phases.size() == 4 && c.nseg == 1 && c.transposed && ops->size() >= 4 && !P.sw.no_cvp_merge) {
       const size_t first = ops->size() - 4;
       bool ok = true;
       for (size_t k = first; k < ops->size(); ++k) {
@@ -713,8 +724,8 @@ struct Builder {
 
   void emit_conv_bwd(ConvRec& c) {
     {
-      const bool defer_on = getenv("DMM_DEFER_WGRAD") != nullptr && atoi(getenv("DMM_DEFER_WGRAD")) != 0;   // (read per plan build; OFF by default, see above)
-      const char* defer_at = getenv("DMM_DEFER_AT");
+      const bool defer_on = P.sw.defer_wgrad;   // (OFF by default, see above)
+      const char* defer_at = lab_str("DMM_DEFER_AT");
       const bool late = c.wname.rfind("decoder.", 0) == 0 || c.wname.rfind("dec_out_to_heat_maps.", 0) == 0;
       const bool flush_here = defer_at ? c.wname.find(defer_at) != std::string::npos : !late;
       if (flush_here) flush_deferred();
@@ -743,7 +754,7 @@ struct Builder {
     Op second_pass;
     int second_buf = -1;
     if (c.wgrad_transposed && dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.nseg == 1 && c.seg[0].C == 128 &&
-        c.seg[0].dgrad == DG_FLIP && getenv("DMM_NO_EFF_COMPACT") == nullptr)
+        c.seg[0].dgrad == DG_FLIP && !P.sw.no_eff_compact)
       eff_compact = wptr<uint8_t>((size_t)c.B * c.Ho * c.Wo * 32 * esz);
     if (c.wgrad_transposed) {
       Op& o = push(OP_WGRAD);
@@ -758,7 +769,7 @@ struct Builder {
       a.dpack = (float*)pd.dpack;
       // wg3.hip's per-workgroup slots: ONE buffer for all launches of the family (they run in order on one stream, each followed
       // by its reduction).  Reserved by the shape alone: the sizing pass and the bound pass must take the same bytes.
-      if (dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.seg[0].C == 128 && getenv("DMM_WG3_SLOTS_OFF") == nullptr) {
+      if (dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.seg[0].C == 128 && !lab_flag("DMM_WG3_SLOTS_OFF")) {
         if (!wg3_part_taken) { wg3_part = wptr<float>((size_t)W3_MAX_SLOTS * W3_SLOT_FLOATS); wg3_part_taken = true; }
         a.part = wg3_part;
         a.part_slots = W3_MAX_SLOTS;
@@ -778,7 +789,7 @@ struct Builder {
     // pass over the output gradient (wg5.hip) instead of four generic launches that each re-gather a quarter of it tap by tap.  Its
     // result goes to phase 0's packed gradient (the phases' packed gradients are summed into the master weights by unpack).
     const bool raw_once = c.nseg == 2 && c.phases.size() == 4 && c.shared_master && c.seg[1].C == 8 && c.seg[1].istride == 2 &&
-                          c.ostride == 2 && getenv("DMM_NO_RAW_ONCE") == nullptr;
+                          c.ostride == 2 && !lab_flag("DMM_NO_RAW_ONCE");
     const int wseg = raw_once ? 1 : c.nseg;
     for (auto& ph : c.phases) {
       Op& o = push(OP_WGRAD);
@@ -804,7 +815,7 @@ struct Builder {
     }
     // Four phases with four taps each, all on wgp.hip (the head's 3x3 over the upsampled decoder output): ONE launch, the phases
     // of a tile range side by side on one XCD - the half-resolution input (0.8 GB at C2) comes from HBM once instead of four times.
-    if (!defer_scope && c.phases.size() == 4 && wseg == 1 && ops->size() >= 4 && getenv("DMM_NO_WGP_MERGE") == nullptr) {
+    if (!defer_scope && c.phases.size() == 4 && wseg == 1 && ops->size() >= 4 && !P.sw.no_wgp_merge) {
       const size_t first = ops->size() - 4;
       bool ok = true;
       for (size_t k = first; k < ops->size(); ++k) {
@@ -919,7 +930,7 @@ struct Builder {
         // reductions only (nothing stored); finalize (q, r); second pass: the same launch stores the FINAL gradient
         // s*dz + q + r*x.  Traffic 2 x |x| + |g| instead of |x| + |g| (store) + 2 |g| + |x| (apply_corr).
         if (c3 && !raw && sb.matz && sb.q && !sb.ginit && !sb.materialized && c.nseg == 1 && c.R == 5 && c.S == 5 && dtype != DT_F32 &&
-            getenv("DMM_NO_TWO_PASS") == nullptr) {
+            !P.sw.no_two_pass) {
           second_pass = o;                       // stores; no reductions
           second_pass.c.red1 = nullptr; second_pass.c.red2 = nullptr;
           second_pass.c.eq = sb.q + sr.ch0; second_pass.c.er = sb.r + sr.ch0;
@@ -1055,7 +1066,7 @@ struct Builder {
       int chunks = 0;
       for (int s2 = 0; s2 < dp.nseg; ++s2) chunks += dp.seg[s2].nchunks;
       dp.dpack = zbptr<float>((size_t)chunks * dp.Npad * BK);
-      dp.gw = P.grads + (dp.w - P.params);
+      dp.gw = Pg + (dp.w - Pp);
       P.packs[c.phases[0].pack].gw = nullptr;  // the forward-shaped packed gradient is not produced
     }
     // FLOPs (2*MACs) in the reference's formulation
@@ -1096,7 +1107,7 @@ struct Builder {
       // (round 2: the gradient of a wide layer's bottleneck was re-gathered by two launches x K/128 column tiles; since bw1 reads it
       // once per channel slice, with the slices of a row range on one XCD, materialising it first only adds a pass: DMM_MATZ_DENSE_K)
       // Measured (round 3, C2 b4, same box): threshold 384 / 640 / never: applycorr 2.08 / 1.81 / 1.69 ms, bw1 5.49 / 5.56 / 5.59 ms.
-      static const int matz_k = getenv("DMM_MATZ_DENSE_K") ? atoi(getenv("DMM_MATZ_DENSE_K")) : (1 << 30);
+      static const int matz_k = lab_int("DMM_MATZ_DENSE_K", 1 << 30);
       const int y1 = new_buf(X.B, X.H, X.W, rup(bw, 8), true, true, /*matz=*/K >= matz_k);
       const int n1 = new_bn(q + ".norm1", K);
       bn_range(n1, xb, base, 0, K);
@@ -1264,7 +1275,7 @@ struct Builder {
   // one K segment that spans the whole master, whole 32-channel groups, 1x1 or 3x3, the master contiguous along (k, tap) or (n, tap),
   // and every master tap covered by the group (the parity phases of a ConvTranspose together).  Marks PackDesc::tiled and appends the
   // tiles - 1x1 masters first, then 3x3 (one launch per instantiation) - with descriptor indices relative to `v`.
-  const bool pack_tiles_on = getenv("DMM_NO_PACK_TILES") == nullptr;
+  const bool pack_tiles_on = !P.sw.no_pack_tiles;
   void make_tiles(std::vector<PackDesc>& v, size_t begin, size_t end, std::vector<PackTile>& out, int& nt1, int& nt9) {
     nt1 = nt9 = 0;
     for (size_t i = begin; i < end; ++i) v[i].tiled = 0;
@@ -1369,8 +1380,8 @@ struct Builder {
   // first stream's first launch reached the queue; together with the join behind the full weight pack the main queue sat idle for
   // 2.2 ms at the start of every C3/C4/C5 step (tools/probes/dump_first.py; profiles/r04/ablations.txt section 8).
   size_t s2_recs = 0, concat_rec = 0;
-  const bool s2_overlap = getenv("DMM_NO_S2_OVERLAP") == nullptr;  // A/B knob
-  const bool s2_interleave = getenv("DMM_NO_S2_INTERLEAVE") == nullptr;  // A/B knob
+  const bool s2_overlap = !lab_flag("DMM_NO_S2_OVERLAP");  // lab knob
+  const bool s2_interleave = !P.sw.no_s2_interleave;
   void emit_record(size_t ri, bool on_side) {
     const Rec& r = recs[ri];
     if (pack_split > 0 && ri == pack_cut_rec) { Op& o = push(OP_JOIN); o.epi = 1; tag(o, "other", "join.pack", 0, 0); }
@@ -1451,7 +1462,7 @@ struct Builder {
     }
     if (cur.n > 0) brecs.push_back(cur);
     for (auto& c : convs) brecs[bucket_of(T(c.wname).off)].convs_left++;
-    for (auto& b : bns) brecs[bucket_of(b.dgamma - P.grads)].bns_left++;
+    for (auto& b : bns) brecs[bucket_of(b.dgamma - Pg)].bns_left++;
     // unpack tables: the descriptors that scatter into a master gradient, grouped by bucket
     P.unpacks.clear(); P.unpack_prefix.clear(); P.unpack_tiles.clear();
     for (size_t bi = 0; bi < brecs.size(); ++bi) {
@@ -1459,7 +1470,7 @@ struct Builder {
       bk.first_desc = (int)P.unpacks.size();
       bk.rows = 0;
       for (auto& pd : P.packs) {
-        if (pd.gw == nullptr || pd.dpack == nullptr || bucket_of(pd.gw - P.grads) != (int)bi) continue;
+        if (pd.gw == nullptr || pd.dpack == nullptr || bucket_of(pd.gw - Pg) != (int)bi) continue;
         P.unpacks.push_back(pd);
       }
       bk.ndesc = (int)P.unpacks.size() - bk.first_desc;
@@ -1496,7 +1507,7 @@ struct Builder {
     note_write(b, (int)ops->size() - 1);
   }
   void bn_grad_done(int bn, size_t first_op) {  // called behind the bn_bwd_finalize launches [first_op, end) of a BatchNorm
-    const int b = bucket_of(bns[bn].dgamma - P.grads);
+    const int b = bucket_of(bns[bn].dgamma - Pg);
     brecs[b].bns_left--;
     for (size_t i = first_op; i < ops->size(); ++i) note_write(b, (int)i);
   }
@@ -1515,7 +1526,7 @@ struct Builder {
     std::stable_sort(P.buckets.begin(), P.buckets.end(), [](const GradBucket& a, const GradBucket& b) { return a.ready < b.ready; });
   }
 
-  bool pad_pitch = getenv("DMM_PITCH_PAD") != nullptr;  // measured: no effect on MI355X for this access pattern; off
+  bool pad_pitch = lab_flag("DMM_PITCH_PAD");  // measured: no effect on MI355X for this access pattern; off
   PackDesc* pack_dev = nullptr;
   int* prefix_dev = nullptr;
   int total_rows = 0;          // rows of the pack launch behind the split (all rows without a split)
@@ -1530,12 +1541,11 @@ struct Builder {
     // the row prefix restarts at 0 behind the split).
     pack_split = 0;
     pack_cut_rec = recs.size();
-    if (!recs.empty() && getenv("DMM_NO_PACK_SPLIT") == nullptr) {
+    if (!recs.empty() && !lab_flag("DMM_NO_PACK_SPLIT")) {
       // The cut: the first record behind the point where PACK_EARLY_ELEMS weight elements have been seen (d121/d201: inside dense
       // block 3), not in front of the concat module.  DMM_PACK_CUT=<record index> moves it (1 = the round-3 split behind the stem).
-      const char* pc = getenv("DMM_PACK_CUT");
       size_t cut = recs.size();
-      if (pc) cut = (size_t)std::max(1, atoi(pc));
+      if (P.sw.pack_cut > 0) cut = (size_t)P.sw.pack_cut;
       else {
         double elems = 0;
         for (size_t ri = 0; ri < recs.size(); ++ri) {
@@ -1598,7 +1608,7 @@ struct Builder {
     ops->clear();
     training = true;
     { Op& o = push(OP_MEMSET); o.ms.p = zbbase; o.ms.bytes = 0; /* patched in plan_bind */ }
-    { Op& o = push(OP_MEMSET); o.ms.p = P.grads; o.ms.bytes = (size_t)P.nparams * sizeof(float); }  // unpack may accumulate
+    { Op& o = push(OP_MEMSET); o.ms.p = Pg; o.ms.bytes = (size_t)P.nparams * sizeof(float); }  // unpack may accumulate
     {
       Op& o = push(OP_BCE);
       BceArgs& a = o.bce;
@@ -1628,8 +1638,35 @@ struct Builder {
 // ---------------------------------------------------------------------------------------------------- C-level plan API
 using namespace dmm;
 
+PlanSwitches PlanSwitches::from_environment() {
+  PlanSwitches s;
+  auto on = [](const char* n) { const char* v = getenv(n); return v != nullptr && !(v[0] == '0' && v[1] == 0); };
+  s.no_pack_tiles = on("DMM_NO_PACK_TILES");
+  s.no_hf = on("DMM_NO_HF");
+  s.no_c3_merge = on("DMM_NO_C3_MERGE");
+  s.no_cvp_merge = on("DMM_NO_CVP_MERGE");
+  s.no_wgp_merge = on("DMM_NO_WGP_MERGE");
+  s.no_two_pass = on("DMM_NO_TWO_PASS");
+  s.no_eff_compact = on("DMM_NO_EFF_COMPACT");
+  s.no_s2_interleave = on("DMM_NO_S2_INTERLEAVE");
+  s.defer_wgrad = on("DMM_DEFER_WGRAD");
+  const char* pc = getenv("DMM_PACK_CUT");
+  s.pack_cut = pc ? std::max(1, atoi(pc)) : 0;
+  return s;
+}
+
+namespace {
+// families the plan's switches rule out, in force (thread-local launch control) while a Builder picks kernel families
+struct DenyScope {
+  unsigned saved;
+  explicit DenyScope(const PlanSwitches& sw) : saved(g_ctl.deny) { if (sw.no_hf) g_ctl.deny |= 1u << IMPL_HF; }
+  ~DenyScope() { g_ctl.deny = saved; }
+};
+}  // namespace
+
 void plan_build_tables(dmm_plan* p) {
   build_tensor_table(p->desc, p->tensors, p->nparams, p->nbuf);
+  DenyScope deny(p->sw);
   Builder b(*p, true, nullptr);
   b.build();
   b.emit_all();
@@ -1643,9 +1680,20 @@ void plan_build_tables(dmm_plan* p) {
 void plan_bind(dmm_plan* p, void* ws) {
   p->packs.clear();
   p->fwd_train.clear(); p->fwd_eval.clear(); p->bwd.clear();
+  DenyScope deny(p->sw);
   Builder b(*p, false, (uint8_t*)ws);
   b.build();
   b.emit_all();
+  {  // the bound pass must have taken exactly what the sizing pass reported: anything else means launches that write outside the workspace
+    const size_t z = (b.Z.off + 255) / 256 * 256, zb = (b.ZB.off + 255) / 256 * 256, w = (b.W.off + 255) / 256 * 256;
+    if (z != p->zero_bytes || zb != p->zero_bwd_bytes || w != p->main_bytes) {
+      p->fwd_train.clear(); p->fwd_eval.clear(); p->bwd.clear();
+      throw dmm::plan_sizing_error("plan_bind: the bound pass took " + std::to_string(z) + " / " + std::to_string(zb) + " / " + std::to_string(w) +
+                             " bytes of the three workspace regions, the sizing pass " + std::to_string(p->zero_bytes) + " / " +
+                             std::to_string(p->zero_bwd_bytes) + " / " + std::to_string(p->main_bytes) +
+                             " (an environment switch changed between dmm_plan_create and dmm_plan_bind?)");
+    }
+  }
   // the training forward starts by zeroing the whole accumulator region
   p->fwd_train[0].ms.p = ws;
   p->fwd_train[0].ms.bytes = p->zero_bytes;

@@ -1,5 +1,6 @@
 // Host-side plan of the Dense_U_Net_lidar training step: topology -> buffers -> kernel launch list.
 #pragma once
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -8,6 +9,9 @@
 #include "pointwise.h"
 
 namespace dmm {
+
+// plan_bind: the bound pass did not take the workspace bytes the sizing pass reported (dmm_plan_bind returns DMM_ERR_STATE)
+struct plan_sizing_error : std::runtime_error { using std::runtime_error::runtime_error; };
 
 struct TensorInfo {
   std::string name;
@@ -80,8 +84,32 @@ struct GradBucket {
   int ready = -1;                     // index of the last launch that writes into it
 };
 
+// The run-time switches of a plan, read from the environment ONCE, by dmm_plan_create, and kept in the plan: the sizing pass
+// (create) and the bound pass (bind) cannot disagree about them, and nothing in the library calls getenv while a plan is built or run.
+// Each selects between two correct schedules of the same arithmetic and has an A/B test (tests/test_timed_kernels_gpu.py; the host
+// harness of tests/test_host_cpu.py drives every one through create -> bind -> run -> destroy under AddressSanitizer):
+//   DMM_NO_PACK_TILES=1     weights packed / gradients unpacked by the generic kernels only
+//   DMM_NO_HF=1             the head's first convolution on conv3.hip's one-launch path instead of hf.hip
+//   DMM_NO_C3_MERGE=1       ... as four launches, one per output parity
+//   DMM_NO_CVP_MERGE=1      a decoder ConvTranspose's four parity phases as four launches
+//   DMM_NO_WGP_MERGE=1      the head's weight-gradient phases as four launches
+//   DMM_NO_TWO_PASS=1       the 5x5 data gradient as one pass + apply_corr instead of two passes
+//   DMM_NO_EFF_COMPACT=1    wg3.hip gathers its gradient operand from the block buffers instead of reading conv3.hip's compact copy
+//   DMM_NO_S2_INTERLEAVE=1  mid fusion: the second encoder's launch records behind the first's instead of alternating
+//   DMM_PACK_CUT=<n>        the forward record in front of which the late layers' weight pack is joined (1 = behind the stem)
+//   DMM_DEFER_WGRAD=1       the head's / decoder's multi-tap weight gradients held back until backward reaches the encoder
+// Process-wide (capi.cpp, read when the library is loaded; also dmm_set_option): DMM_NO_OVERLAP, DMM_GRAPH, DMM_GRAD_BUCKET_MB;
+// diagnostics: DMM_TRACE_DESTROY.  Everything else that used to be an environment switch is a compile-time lab knob (common.h).
+struct PlanSwitches {
+  bool no_pack_tiles = false, no_hf = false, no_c3_merge = false, no_cvp_merge = false, no_wgp_merge = false, no_two_pass = false,
+       no_eff_compact = false, no_s2_interleave = false, defer_wgrad = false;
+  int pack_cut = 0;  // 0: by weight count
+  static PlanSwitches from_environment();
+};
+
 struct dmm_plan {
   dmm_model_desc desc;
+  PlanSwitches sw;
   std::vector<dmm::TensorInfo> tensors;
   int64_t nparams = 0, nbuf = 0;
   size_t zero_bytes = 0, zero_bwd_bytes = 0, main_bytes = 0;
@@ -114,8 +142,12 @@ struct dmm_plan {
   int prof_pass[2] = {0, 0};                       // passes recorded for [0] training forward, [1] backward
   std::vector<std::vector<void*>> prof_events[2];  // [which][pass] -> one (start, end) event pair per op
   std::string prof_filter;                         // only ops whose label starts with this are bracketed (empty: all)
-  // weight-gradient GEMMs run on a second stream beside the data-gradient chain (nothing reads them before unpack)
-  std::vector<void*> side_streams, join_events;  // weight gradients are dealt round-robin to these
+  // Streams: the side stream (weight gradients, leaves, the second encoder), the pack stream and the capture stream belong to a
+  // PROCESS-LIFETIME pool per device (capi.cpp: DevicePool) - a plan never creates or destroys a stream.  Events (fork / join /
+  // bucket / profiling) are taken from that pool's free lists on first use and handed back by dmm_plan_destroy.
+  int device = -1;                         // the device the plan was bound on
+  bool used_side = false, used_capture = false;
+  std::vector<void*> join_events;          // [0] side stream, [1] pack stream
   std::vector<void*> fork_events;
   // hipGraph replay of a launch list (capi.cpp: launch_list): instantiated graphs keyed by the caller's pointers of the call
   struct GraphEntry { const void* key[4]; void* exec; unsigned long long stamp; };
@@ -127,7 +159,6 @@ struct dmm_plan {
     unsigned long long epoch = 0;  // option epoch the entries were captured under (dmm_set_option invalidates them)
   };
   GraphCache graphs[2];          // [0] training forward, [1] loss + backward
-  void* capture_stream = nullptr;
   bool graph_failed = false;     // a capture did not work on this plan: stay eager
   bool dp_used = false;          // a data-parallel reducer waits for bucket events: backward stays eager (events must be real)
   unsigned long long graph_clock = 0;

@@ -320,7 +320,7 @@ hipError_t launch_maxpool_bwd(const MaxpoolBwdArgs& a, int dtype, hipStream_t st
   const int rpb = 256 / (a.C / slot);
   const int npix = a.B * a.H0 * a.W0;
   int grid = (npix + rpb - 1) / rpb;
-  static const int cap = getenv("DMM_MPB_GRID") ? atoi(getenv("DMM_MPB_GRID")) : 2048;
+  static const int cap = lab_int("DMM_MPB_GRID", 2048);
   if (grid > cap) grid = cap;  // 8 workgroups per CU: every workgroup ends with 2 C fp64 atomics
   const size_t smem = 2 * a.C * sizeof(double);
   if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(grid), dim3(256), smem, st, a);

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
   }
 }
 
-static bool g_wg3 = getenv("DMM_NO_WG3") == nullptr;
+static bool g_wg3 = !lab_flag("DMM_NO_WG3");
 void wg3_set_enabled(bool on) { g_wg3 = on; }
 
 template <typename T, int PQ>
@@ -391,8 +391,8 @@ hipError_t launch_wg3(const WgradArgs& a, int dtype, hipStream_t st) {
   // fp32 atomics at the chip-wide atomic rate of 1.3 TB/s = 0.11 us): minimum at nwg ~ sqrt(t_tile / 0.11 us * tiles), t_tile ~ 1.3 us.
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const bool use_slots = getenv("DMM_WG3_SLOTS") == nullptr || atoi(getenv("DMM_WG3_SLOTS")) != 0;
-  static const int wgs_cap = getenv("DMM_WG3_WGS") ? atoi(getenv("DMM_WG3_WGS")) : 0;
+  static const bool use_slots = lab_int("DMM_WG3_SLOTS", 1) != 0;
+  static const int wgs_cap = lab_int("DMM_WG3_WGS", 0);
   g.part = (use_slots && a.part != nullptr) ? a.part : nullptr;
   int nwg = g.part ? std::min(cus, a.part_slots) : (int)std::lround(std::sqrt(12.0 * g.ntiles));
   if (wgs_cap > 0) nwg = std::min(nwg, wgs_cap);

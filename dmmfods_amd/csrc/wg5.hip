@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   }
 }
 
-static bool g_wg5 = getenv("DMM_NO_WG5") == nullptr;
+static bool g_wg5 = !lab_flag("DMM_NO_WG5");
 void wg5_set_enabled(bool on) { g_wg5 = on; }
 
 
@@ -270,7 +270,7 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   g.ntiles = a.B * g.tiles_y * g.tiles_x;
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const int per_cu = getenv("DMM_WG5_PER_CU") ? atoi(getenv("DMM_WG5_PER_CU")) : 2;
+  static const int per_cu = lab_int("DMM_WG5_PER_CU", 2);
   // every workgroup ends with 57 (stem: 106) KB of atomics; a tile costs ~1 us: two workgroups per CU unless the picture is small
   int nwg = std::max(1, std::min((stem ? 1 : per_cu) * cus, g.ntiles / 8));  // (the stem form holds one workgroup per CU)
   g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;

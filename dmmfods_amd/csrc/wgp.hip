@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
   }
 }
 
-static bool g_wgp = getenv("DMM_NO_WGP") == nullptr;
+static bool g_wgp = !lab_flag("DMM_NO_WGP");
 void wgp_set_enabled(bool on) { g_wgp = on; }
 
 
@@ -280,7 +280,7 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   if (!family_on(g_wgp, IMPL_WGP) || dtype == DT_F32 || a.nseg < 1 || a.nseg > 2) return hipErrorNotSupported;
   const Seg& x = a.seg[0];
   const Seg& y = a.dy;
-  static const bool trace = getenv("DMM_WGP_TRACE") != nullptr;
+  static const bool trace = lab_flag("DMM_WGP_TRACE");
   if (trace && !g_ctl.dry)
     fprintf(stderr, "wgp? nseg %d x: mode %d istride %d Hs %d Ws %d (Ho %d Wo %d) scale %d C %d Cpad %d ntaps %d | y: mode %d ntaps %d istride %d Hs %d Ws %d C %d | N %d Npad %d\n",
             a.nseg, x.mode, x.istride, x.Hs, x.Ws, a.Ho, a.Wo, x.scale != nullptr, x.C, x.Cpad, x.ntaps, y.mode, y.ntaps, y.istride, y.Hs, y.Ws, y.C, a.N, a.Npad);
@@ -328,7 +328,7 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   // one workgroup per CU (its accumulators fill the register file); every workgroup ends with NTAP x 128 x NCO x 4 bytes of atomics
   static const int cus = [] { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev);
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  static const int target = getenv("DMM_WGP_WGS") ? atoi(getenv("DMM_WGP_WGS")) : 0;
+  static const int target = lab_int("DMM_WGP_WGS", 0);
   const int pairs = g.nct * g.ncot;
   const int nph = std::max(1, a.nphase);
   for (int ph = 0; ph < 4; ++ph) { g.ph_dymin[ph] = ph_dymin[ph]; g.ph_dxmin[ph] = ph_dxmin[ph]; }

@@ -488,7 +488,7 @@ hipError_t launch_wgrad(WgradArgs a, int dtype, bool mfma, hipStream_t st, int i
     const int base = a.kgroups * (a.Npad / wbn);
     // ~256 workgroups for short row ranges (fewer, longer workgroups also leave the other stream more room) (every workgroup ends with WBN x 128 atomics); long ranges are cut finer, down
     // to 32 row steps per workgroup, which evens out the tail of the launch
-    static const int target = getenv("DMM_WGRAD_WGS") ? atoi(getenv("DMM_WGRAD_WGS")) : 256;
+    static const int target = lab_int("DMM_WGRAD_WGS", 256);
     const int steps = (a.M + bmw - 1) / bmw;
     const int want = (target + base - 1) / base, want_hi = (8 * target + base - 1) / base;
     int per = (steps + want - 1) / want;

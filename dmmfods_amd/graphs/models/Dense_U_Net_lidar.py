@@ -80,11 +80,17 @@ class _Plan:
             self._raw[:self._guard].fill_(0xA5)
             self._raw[self._guard + nbytes:].fill_(0xA5)
         self.workspace = self._raw[self._guard:self._guard + nbytes]
+        self._alloc_stream = torch.cuda.current_stream(dev)
+        self._streams = set()
         nc = int(model.num_classes)
         self.metrics = torch.zeros(2 * nc + batch * 2 * nc, dtype=torch.float64, device=dev)
         self.flops_forward = L.dmm_plan_forward_flops(self.handle)
-        _lib.check(L.dmm_plan_bind(self.handle, self.workspace.data_ptr(), nbytes, model._param_arena.data_ptr(),
-                                   model._grad_arena.data_ptr(), model._buffer_arena.data_ptr()))
+        try:
+            _lib.check(L.dmm_plan_bind(self.handle, self.workspace.data_ptr(), nbytes, model._param_arena.data_ptr(),
+                                       model._grad_arena.data_ptr(), model._buffer_arena.data_ptr()))
+        except Exception:
+            self.close()
+            raise
         self.loss_key = None
         # gradient buckets in the order backward finishes them: (offset, count) in elements of the gradient arena
         self.grad_buckets = []
@@ -100,16 +106,43 @@ class _Plan:
         g = self._guard
         return bool((self._raw[:g] == 0xA5).all()) and bool((self._raw[g + self.workspace.numel():] == 0xA5).all())
 
+    def note_stream(self):
+        """Remember the torch stream a launch list is about to be enqueued on (close() orders the workspace's release behind it)."""
+        st = torch.cuda.current_stream(self._raw.device)
+        if st != self._alloc_stream:
+            self._streams.add(st)
+
+    @property
+    def closed(self):
+        return not self.handle
+
+    def close(self):
+        """Destroy the plan NOW, at a known statement: dmm_plan_destroy synchronises the library's helper streams, hands the plan's
+        events back to the process pool and frees the host structures; then the workspace goes back to torch's allocator (which
+        orders its reuse behind the stream it was allocated on; any other stream the plan was run on is recorded).  Raises DmmError
+        if a HIP call of the teardown failed - the plan is gone either way.  Idempotent."""
+        if not self.handle:
+            return
+        h, self.handle = self.handle, None
+        rc = _lib.lib().dmm_plan_destroy(h)
+        for st in self._streams:
+            self._raw.record_stream(st)
+        self._streams.clear()
+        self.workspace = self._raw = self.metrics = None
+        _lib.check(rc)
+
     def __del__(self):
-        # (not while the interpreter shuts down: the HIP runtime may already be gone by then - destroying the plan's streams and events
-        # behind it is a segmentation fault waiting for the right finalisation order; the process's exit frees everything anyway)
+        # Fallback only: plans are closed explicitly (Dense_U_Net_lidar.close(), eviction from the plan cache, _apply()).  A plan
+        # that is still open when the garbage collector finds it is closed here and the fact is reported, never swallowed.  While the
+        # interpreter is finalising nothing is done: module globals (ctypes, torch, this module's _lib) may already be gone, and
+        # the process's exit releases the plan - NOT because the HIP runtime would be unloaded (it is not: round 4's guess, DESIGN 2a).
+        import sys
+        if sys is None or sys.is_finalizing() or not getattr(self, "handle", None):
+            return
         try:
-            import sys
-            if self.handle and not sys.is_finalizing():
-                _lib.lib().dmm_plan_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+            self.close()
+        except Exception as e:  # noqa: BLE001 - a destructor must not raise; say what happened instead
+            sys.stderr.write(f"[dmmfods_amd] closing a plan from the garbage collector failed: {e!r}\n")
 
 
 class _HipBackward(torch.autograd.Function):
@@ -124,6 +157,9 @@ class _HipBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_logits):
         model, plan = ctx.model, ctx.plan
+        if plan.closed:
+            raise RuntimeError("backward() through a forward whose plan has been closed (model.close() or a size change in between)")
+        plan.note_stream()
         g = grad_logits.contiguous().float()
         _lib.check(_lib.lib().dmm_plan_backward(plan.handle, g.data_ptr(), _lib.stream_ptr()))
         model._attach_grads()
@@ -179,7 +215,7 @@ class Dense_U_Net_lidar(nn.Module):
             table = _tensor_table(h)
             nparams, nbuf = L.dmm_plan_num_params(h), L.dmm_plan_num_buffer_elems(h)
         finally:
-            L.dmm_plan_destroy(h)
+            _lib.check(L.dmm_plan_destroy(h))
         self._table = table
         self._param_arena = torch.zeros(nparams, dtype=torch.float32)
         self._grad_arena = torch.zeros(nparams, dtype=torch.float32)
@@ -279,9 +315,27 @@ class Dense_U_Net_lidar(nn.Module):
                 owner._buffers[leaf] = self._buffer_arena[off:off + n].view(shape)
             else:
                 owner._buffers[leaf] = self._tracked_arena[off]
+        self.close()   # the plans were bound to the old arenas
+        return self
+
+    def close(self):
+        """Release every execution plan of this model (GPU workspaces of several GB each, the library's launch lists) at a known
+        point.  The model stays usable: the next forward() builds a new plan.  The reference has no counterpart (it never frees
+        anything explicitly, A:442-450); call it when a model is dropped or before the input size changes for good."""
+        plans = list(getattr(self, "_plans", {}).values())
+        last = getattr(self, "_last", None)
+        if last is not None and last[0] not in plans:
+            plans.append(last[0])
         self._plans = OrderedDict()
         self._last = None
-        return self
+        err = None
+        for pl in plans:
+            try:
+                pl.close()
+            except Exception as e:  # noqa: BLE001 - close them all, then report the first failure
+                err = err or e
+        if err is not None:
+            raise err
 
     def _attach_grads(self):
         for owner, leaf, kind, shape, off in self._slots:
@@ -304,7 +358,10 @@ class Dense_U_Net_lidar(nn.Module):
         plan = self._plans.get(key)
         if plan is None:
             while len(self._plans) >= 2:  # each plan owns a multi-GB workspace
-                self._plans.popitem(last=False)
+                _, old = self._plans.popitem(last=False)
+                if self._last is not None and self._last[0] is old:
+                    self._last = None
+                old.close()
             plan = _Plan(self, batch, height, width)
             self._plans[key] = plan
         else:
@@ -334,6 +391,7 @@ class Dense_U_Net_lidar(nn.Module):
                 raise RuntimeError(f"stream_2 has {x2.shape[1]} channels, expected {self.stream_2_in_channels}")
             x2 = x2.contiguous().float()
         plan = self._get_plan(B, H, W)
+        plan.note_stream()
         logits = torch.empty(B, self.num_classes, H, W, dtype=torch.float32, device=x1.device)
         _lib.check(_lib.lib().dmm_plan_forward(plan.handle, x1.data_ptr(), x2.data_ptr() if x2 is not None else None,
                                                logits.data_ptr(), 1 if self.training else 0, _lib.stream_ptr()))
@@ -351,6 +409,9 @@ class Dense_U_Net_lidar(nn.Module):
         if self._last is None:
             raise RuntimeError("loss_backward() needs a preceding training-mode forward()")
         plan, logits = self._last
+        if plan.closed:
+            raise RuntimeError("the plan of the last forward() has been closed")
+        plan.note_stream()
         t = target.contiguous().float()
         self._apply_loss(plan)
         _lib.check(_lib.lib().dmm_plan_loss_backward(plan.handle, logits.data_ptr(), t.data_ptr(), plan.metrics.data_ptr(),

@@ -83,7 +83,14 @@ int dmm_set_option(const char* name, int value);
 
 /* Plan construction needs no GPU: it derives the layer table, the state_dict layout and the workspace size. */
 int dmm_plan_create(const dmm_model_desc* desc, dmm_plan** out);
-void dmm_plan_destroy(dmm_plan* plan);
+/* Teardown (nothing upstream: the reference never frees a model explicitly, agents/Dense_U_Net_lidar_Agent.py:442-450).  The call
+ * first SYNCHRONISES every helper stream the plan has launched on, so when it returns nothing the library enqueued outside the
+ * caller's own stream still touches the workspace or the arenas; what was enqueued on the `stream` arguments of earlier calls is
+ * the caller's to order before it frees those buffers.  The plan owns no stream: the helper streams belong to a per-device,
+ * process-lifetime pool and the plan's events go back to it.  Returns DMM_OK, or DMM_ERR_HIP naming the first HIP call that
+ * failed - the plan is gone either way and the handle must not be used again.  dmm_plan_destroy(NULL) is DMM_OK.
+ * DMM_TRACE_DESTROY=1 in the environment writes one line per teardown step to stderr. */
+int dmm_plan_destroy(dmm_plan* plan);
 
 /* state_dict layout, in the reference's registration order */
 int dmm_plan_num_tensors(const dmm_plan* plan);

@@ -294,11 +294,11 @@ def test_thin_logits_kernel_matches_generic_kernels():
         out = {}
         for on in (1, 0):
             _lib.check(_lib.lib().dmm_set_option(b"thin_logits", on))
-            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
+            model.close()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 out[on] = model(rgb, lidar).clone()
         _lib.check(_lib.lib().dmm_set_option(b"thin_logits", 1))
-        model._plans.clear()
+        model.close()
         scale = float(out[0].abs().max())
         assert scale > 0 and torch.isfinite(out[1]).all()
         assert float((out[1] - out[0]).abs().max()) <= 3e-4 * scale + 1e-5, (H, W, float((out[1] - out[0]).abs().max()), scale)
@@ -387,7 +387,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"conv3", on))
-            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
+            model.close()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 logits = model(rgb, lidar).clone()
             met = model.loss_backward(tgt)
@@ -396,7 +396,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
             model._tracked_arena.zero_()
     finally:
         _lib.check(L.dmm_set_option(b"conv3", 1))
-        model._plans.clear()
+        model.close()
     assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][2]).all()
     tol = 1e-2 if dtype == "fp16" else 1.6e-2   # measured 3.1e-3 / 0 on the logits, 4.9e-3 / 3e-4 on the gradients
     e_log = _rel(out[1][0], out[0][0])
@@ -412,7 +412,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wg3", on))
-            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
+            model.close()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
@@ -420,7 +420,7 @@ def test_conv3_halo_kernels_match_generic_kernels(dtype):
             grads[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if k.endswith("conv2.weight")}
     finally:
         _lib.check(L.dmm_set_option(b"wg3", 1))
-        model._plans.clear()
+        model.close()
     worst = max(((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm()).item() for k in grads[1])
     print(f"   wg3 vs generic on identical operands: worst conv2.weight gradient rel L2 {worst:.3e}")
     assert len(grads[1]) >= 9 and worst < 2e-4
@@ -447,7 +447,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wgp", on))
-            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
+            model.close()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
@@ -463,7 +463,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
                     labels.append((label.value or b"").decode())
     finally:
         _lib.check(L.dmm_set_option(b"wgp", 1))
-        model._plans.clear()
+        model.close()
     on_wgp = [x for x in labels if x.startswith("wgp.")]
     assert len(on_wgp) >= 3 * 4, on_wgp                       # 3 multi-tap phases x 4 ConvTranspose stages (+ the head's 4 if eligible)
     assert len(grads[1]) == 5
@@ -478,7 +478,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(b"wg5", on))
-            model._plans.clear()                     # a plan fixes the kernel family of every launch when it is bound
+            model.close()                     # a plan fixes the kernel family of every launch when it is bound
             with torch.no_grad():
                 model(rgb, lidar)
             model.loss_backward(tgt)
@@ -486,7 +486,7 @@ def test_parity_phase_weight_gradient_kernel_matches_generic(dtype):
             g5[on] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if k in names}
     finally:
         _lib.check(L.dmm_set_option(b"wg5", 1))
-        model._plans.clear()
+        model.close()
     assert sorted(x.split("/")[1] for x in labels if x.startswith("wg5.")) == ["f.conv0", "h.refine0.raw", "h.refine1"], [x for x in labels if x.startswith("wg5.")]
     for k in names:
         e5 = ((g5[1][k] - g5[0][k]).norm() / g5[0][k].norm()).item()
@@ -516,7 +516,7 @@ def test_fused_dense_layer_backward_matches_separate_kernels(opt, dtype):
     try:
         for on in (1, 0):
             _lib.check(L.dmm_set_option(opt.encode(), on))
-            model._plans.clear()                     # the fusion is decided when the plan is built
+            model.close()                     # the fusion is decided when the plan is built
             with torch.no_grad():
                 model(rgb, lidar)
             met = model.loss_backward(tgt)
@@ -532,7 +532,7 @@ def test_fused_dense_layer_backward_matches_separate_kernels(opt, dtype):
             model._tracked_arena.zero_()
     finally:
         _lib.check(L.dmm_set_option(opt.encode(), 1))
-        model._plans.clear()
+        model.close()
     assert out[1][2] >= 58 and out[0][2] == 0, (out[1][2], out[0][2])      # every dense layer of DenseNet-121 (+ a 128-wide decoder 1x1)
     assert _rel(out[1][0], out[0][0]) < 1e-6                                # the forward pass is untouched
     g1, g0 = out[1][1], out[0][1]
@@ -566,7 +566,7 @@ def test_graph_replay_matches_eager(dtype, variant):
     try:
         for mode in (0, 1):
             _lib.check(L.dmm_set_option(b"graph", mode))
-            model._plans.clear()
+            model.close()
             res = []
             keep = []                       # (different logits / input tensors every step: the replayed segment touches no caller pointer)
             for step in range(8):
@@ -582,10 +582,69 @@ def test_graph_replay_matches_eager(dtype, variant):
             out[mode] = (res, L.dmm_plan_num_graph_replays(plan.handle, 0), L.dmm_plan_num_graph_replays(plan.handle, 1))
     finally:
         _lib.check(L.dmm_set_option(b"graph", 0))      # (the default)
-        model._plans.clear()
+        model.close()
     assert out[0][1] == 0 and out[0][2] == 0
     assert out[1][1] >= 4 and out[1][2] >= 4, out[1][1:]        # the later steps were replays
     for (lg0, ls0, g0), (lg1, ls1, g1) in zip(out[0][0], out[1][0]):
         assert float((lg0 - lg1).abs().max()) <= 1e-6 * float(lg0.abs().max())
         assert _rel(ls1, ls0) < 1e-6
         assert ((g1 - g0).norm() / g0.norm()).item() < (1e-5 if dtype == "fp32" else 2e-3)
+
+
+def test_plan_lifetime_is_explicit_and_teardown_is_traced(capfd):
+    """Round 5: GPU objects are released at a known statement.  `model.close()` destroys every plan of the
+    model - dmm_plan_destroy synchronises the library's helper streams, returns its events to the process pool and reports any failing
+    HIP call as DmmError instead of a swallowed exception in a garbage-collected __del__; the model stays usable (the next forward
+    builds a new plan with the same results), evicting a plan from the cache and moving the model close its plans too, a closed plan
+    refuses a late backward, and DMM_TRACE_DESTROY names every teardown step on stderr."""
+    from oracle import restatement as R
+    arch = _arch(R, TINY, "mid3")
+    model = _model(arch)
+    model.load_state_dict(R.make_state(arch, seed=123))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=0))
+    with torch.no_grad():
+        l0 = model(rgb, lidar).clone()
+    model.loss_backward(tgt)
+    g0 = model.grad_arena.clone()
+    plan = model._last[0]
+    assert not plan.closed
+    model.close()                      # no synchronize in front of it: the teardown orders itself
+    assert plan.closed and model._last is None and len(model._plans) == 0
+    plan.close()                       # idempotent
+    with pytest.raises(RuntimeError):
+        model.loss_backward(tgt)       # needs a new training forward
+    with torch.no_grad():
+        l1 = model(rgb, lidar).clone()
+    model.loss_backward(tgt)
+    assert torch.equal(l0, l1)
+    assert ((model.grad_arena - g0).norm() / g0.norm()).item() < 1e-5
+    # the autograd route keeps a reference to its plan: closing in between is an error at backward, not a crash
+    out = model(rgb, lidar)
+    model.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        out.sum().backward()
+    # the plan cache holds two plans: a third size closes the oldest
+    sizes = [(64, 96), (96, 96), (64, 128)]
+    plans = []
+    for H, W in sizes:
+        r, l, t = (x.to(DEV) for x in R.make_inputs(arch, 1, H, W, seed=1))
+        with torch.no_grad():
+            model(r, l)
+        plans.append(model._last[0])
+    assert plans[0].closed and not plans[1].closed and not plans[2].closed
+    model.float()                      # _apply re-points the arenas: the plans bound to the old ones are closed
+    assert all(p.closed for p in plans)
+    torch.cuda.synchronize()
+    # breadcrumbs (read by the library when it was loaded or at the first teardown: run in a child so the variable is seen)
+    import subprocess, sys
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from tests.test_model_gpu import _arch, _model, TINY\n"
+            "from oracle import restatement as R\n"
+            "a = _arch(R, TINY, 'no'); m = _model(a).to('cuda').train()\n"
+            "r, l, t = (x.to('cuda') for x in R.make_inputs(a, 1, 64, 96, seed=0))\n"
+            "m(r, l); m.loss_backward(t); m.close(); print('closed ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DMM_TRACE_DESTROY="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "closed ok" in res.stdout, res.stderr[-2000:]
+    for step in ("begin", "synchronise the side stream", "events back to the pool", "delete", "done"):
+        assert f"[dmm] destroy: {step}" in res.stderr, (step, res.stderr[-2000:])

@@ -258,7 +258,7 @@ def test_wg3_reads_the_compact_effective_gradient_bit_for_bit(dtype, monkeypatch
             monkeypatch.setenv("DMM_NO_EFF_COMPACT", "1")
         else:
             monkeypatch.delenv("DMM_NO_EFF_COMPACT", raising=False)
-        model._plans.clear()
+        model.close()
         model._tracked_arena.zero_() if hasattr(model, "_tracked_arena") else None
         model(rgb, lidar)
         model.loss_backward(tgt)
@@ -267,7 +267,7 @@ def test_wg3_reads_the_compact_effective_gradient_bit_for_bit(dtype, monkeypatch
         assert sum(lab.startswith("wg3.") for lab in labels) == 4
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_NO_EFF_COMPACT", raising=False)
-    model._plans.clear()
+    model.close()
     for k in grads[0]:
         if k.endswith("conv2.weight"):    # wg3's results: no float atomics anywhere on their path
             assert torch.equal(grads[0][k], grads[1][k]), (k, float((grads[0][k] - grads[1][k]).abs().max()))
@@ -294,14 +294,14 @@ def test_two_pass_batchnorm_backward_of_the_head(dtype, tol, monkeypatch):
             monkeypatch.setenv("DMM_NO_TWO_PASS", "1")
         else:
             monkeypatch.delenv("DMM_NO_TWO_PASS", raising=False)
-        model._plans.clear()
+        model.close()
         model(rgb, lidar)
         model.loss_backward(tgt)
         torch.cuda.synchronize()
         labels[off] = plan_labels(model._last[0])
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_NO_TWO_PASS", raising=False)
-    model._plans.clear()
+    model.close()
     n_on = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[0])
     n_off = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[1])
     assert (n_on, n_off) == (2, 1), (n_on, n_off)
@@ -331,7 +331,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
             monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
         else:
             monkeypatch.setenv("DMM_DEFER_WGRAD", "1")
-        model._plans.clear()
+        model.close()
         model(rgb, lidar)
         model.loss_backward(tgt)
         torch.cuda.synchronize()
@@ -339,7 +339,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
     monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
-    model._plans.clear()
+    model.close()
     assert sorted(labels[0]) == sorted(labels[1])
     first_head_w = {o: next(i for i, lab in enumerate(labels[o]) if lab.startswith(("wgp.", "wg5.")) and "/h." in lab) for o in (0, 1)}
     last_dec_dgrad = {o: max(i for i, lab in enumerate(labels[o]) if ".bnbwd" in lab and "/d." in lab) for o in (0, 1)}
@@ -365,7 +365,7 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
             monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")
         else:
             monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
-        model._plans.clear()
+        model.close()
         model(rgb, lidar)
         model.loss_backward(tgt)
         torch.cuda.synchronize()
@@ -373,7 +373,7 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
         nl[off] = sum(lab.startswith("wgp.") and lab.endswith("h.refine0") for lab in labels)
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
-    model._plans.clear()
+    model.close()
     assert (nl[0], nl[1]) == (1, 4), nl
     k = "dec_out_to_heat_maps.refine0.weight"
     assert float(grads[1][k].abs().max()) > 0
@@ -401,14 +401,14 @@ def test_head_forward_phases_in_one_launch(dtype, monkeypatch):
             monkeypatch.setenv("DMM_NO_C3_MERGE", "1")
         else:
             monkeypatch.delenv("DMM_NO_C3_MERGE", raising=False)
-        model._plans.clear()
+        model.close()
         with torch.no_grad():
             outs[off] = model(rgb, lidar).clone()
         torch.cuda.synchronize()
         labels = plan_labels(model._last[0])
         nl[off] = sum(lab.startswith("conv3.store") and lab.endswith("h.refine0") for lab in labels)
     monkeypatch.delenv("DMM_NO_C3_MERGE", raising=False)
-    model._plans.clear()
+    model.close()
     assert (nl[0], nl[1]) == (1, 4), nl
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
@@ -434,7 +434,7 @@ def test_mid_fusion_forward_interleaves_the_encoders_and_packs_late_weights_asid
         else:
             monkeypatch.setenv("DMM_PACK_CUT", "16")   # (the test net is far below the element count that places the cut by itself)
             monkeypatch.delenv("DMM_NO_S2_INTERLEAVE", raising=False)
-        model._plans.clear()
+        model.close()
         for _ in range(2):   # the second pass runs with the streams and events of the first already made
             with torch.no_grad():
                 logits = model(rgb, lidar).clone()
@@ -444,7 +444,7 @@ def test_mid_fusion_forward_interleaves_the_encoders_and_packs_late_weights_asid
         labels[old] = plan_labels(model._last[0], lists=(0,))   # the training forward list
     monkeypatch.delenv("DMM_PACK_CUT", raising=False)
     monkeypatch.delenv("DMM_NO_S2_INTERLEAVE", raising=False)
-    model._plans.clear()
+    model.close()
     new, oldl = labels[0], labels[1]
     assert sorted(l for l in new if not l.startswith(("other", "pack"))) == sorted(l for l in oldl if not l.startswith(("other", "pack")))
     s1 = [i for i, l in enumerate(new) if "/f.b1." in l]
@@ -482,14 +482,14 @@ def test_pack_and_unpack_tile_kernels_against_the_generic_kernels(dtype, monkeyp
             monkeypatch.setenv("DMM_NO_PACK_TILES", "1")
         else:
             monkeypatch.delenv("DMM_NO_PACK_TILES", raising=False)
-        model._plans.clear()
+        model.close()
         with torch.no_grad():
             logits = model(rgb, lidar).clone()
         model.loss_backward(tgt)
         torch.cuda.synchronize()
         res[generic] = (logits, {n: p.grad.detach().double().clone() for n, p in model.named_parameters()})
     monkeypatch.delenv("DMM_NO_PACK_TILES", raising=False)
-    model._plans.clear()
+    model.close()
     (l0, g0), (l1, g1) = res[0], res[1]
     assert torch.isfinite(l0).all() and float(l0.abs().max()) > 0
     assert torch.equal(l0, l1), float((l0 - l1).abs().max())
@@ -515,14 +515,14 @@ def test_decoder_transposed_convolution_phases_in_one_launch(monkeypatch):
             monkeypatch.setenv("DMM_NO_CVP_MERGE", "1")
         else:
             monkeypatch.delenv("DMM_NO_CVP_MERGE", raising=False)
-        model._plans.clear()
+        model.close()
         with torch.no_grad():
             outs[off] = model(rgb, lidar).clone()
         torch.cuda.synchronize()
         labels = plan_labels(model._last[0], lists=(0,))
         nl[off] = sum(lab.startswith("cvp.store") for lab in labels)
     monkeypatch.delenv("DMM_NO_CVP_MERGE", raising=False)
-    model._plans.clear()
+    model.close()
     assert (nl[0], nl[1]) == (4, 16), nl
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
@@ -547,7 +547,7 @@ def test_head_first_convolution_wave_specialised_kernel(dtype, monkeypatch):
             monkeypatch.setenv("DMM_NO_HF", "1")
         else:
             monkeypatch.delenv("DMM_NO_HF", raising=False)
-        model._plans.clear()
+        model.close()
         with torch.no_grad():
             outs[k] = model(rgb, lidar).clone()
         torch.cuda.synchronize()
@@ -555,7 +555,7 @@ def test_head_first_convolution_wave_specialised_kernel(dtype, monkeypatch):
         nhf[k] = sum(lab.startswith("hf.store") and lab.endswith("h.refine0") for lab in labels)
         nc3[k] = sum(lab.startswith("conv3.store") and lab.endswith("h.refine0") for lab in labels)
     monkeypatch.delenv("DMM_NO_HF", raising=False)
-    model._plans.clear()
+    model.close()
     assert (nhf["hf"], nc3["hf"], nhf["conv3"], nc3["conv3"]) == (1, 0, 0, 1), (nhf, nc3)
     assert torch.isfinite(outs["hf"]).all() and float(outs["hf"].abs().max()) > 0
     assert torch.equal(outs["hf"], outs["hf2"]), "hf.hip is not reproducible"

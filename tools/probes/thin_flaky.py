@@ -18,11 +18,11 @@ for seed in (0, 1, 2):
         outs = []
         for on in (1, 1, 0, 0, 1):
             _lib.check(_lib.lib().dmm_set_option(b"thin_logits", on))
-            model._plans.clear()
+            model.close()
             with torch.no_grad():
                 outs.append((on, model(rgb, lidar).clone()))
         _lib.check(_lib.lib().dmm_set_option(b"thin_logits", 1))
-        model._plans.clear()
+        model.close()
         scale = float(outs[0][1].abs().max())
         line = []
         for i in range(len(outs)):
