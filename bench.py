@@ -103,10 +103,16 @@ def dominant_class(classes):
     return max(named.items(), key=lambda kv: kv[1]["ms"])
 
 
+def _source_stamp():
+    from tools.src_hash import source_hash
+    return source_hash()
+
+
 def measured_traffic(cls, workload):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py); bench.py cannot run the profiler around itself, so the figure comes from profiles/ and is only
-    used when it was collected on the same workload."""
+    used when it was collected on the same workload.  Returns (bytes per launch, file, PMC class, stale): `stale` when the file
+    carries no source stamp or one of another build (tools/src_hash.py) - the figure is then reported under another key."""
     import glob
     import json as _json
     for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "*pmc_hbm_traffic.json")), reverse=True):
@@ -123,14 +129,15 @@ def measured_traffic(cls, workload):
         if e is None and cls.startswith("bw1."):   # one kernel, labelled by the padded input width in the plan: the PMC class is "bw1"
             e, pmc_cls = d.get("classes", {}).get("bw1"), "bw1 (all launches of the kernel: the profiler sees the kernel name, not the plan's n128 / n64 label)"
         if e:
-            return e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))), pmc_cls
+            return (e["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))), pmc_cls,
+                    d.get("source_sha16") != _source_stamp())
     return None
 
 
 def in_step_kernel_sum(workload):
     """Sum of all kernel durations per step, both streams, from the committed rocprofv3 --kernel-trace --stats summary of this
     workload (profiles/*/<config>_b<batch>_kernel_stats.json, written by tools/profile_round.sh next to the CSV; bench.py cannot
-    wrap itself in the profiler)."""
+    wrap itself in the profiler).  Returns (ms per step, file, stale) - see measured_traffic."""
     import glob
     import json as _json
     here = os.path.dirname(os.path.abspath(__file__))
@@ -140,7 +147,7 @@ def in_step_kernel_sum(workload):
         except Exception:  # noqa: BLE001
             continue
         if (d.get("config"), d.get("batch"), d.get("dtype")) == workload and d.get("steps"):
-            return round(d["total_kernel_ms"] / d["steps"], 3), os.path.relpath(path, here)
+            return round(d["total_kernel_ms"] / d["steps"], 3), os.path.relpath(path, here), d.get("source_sha16") != _source_stamp()
     return None
 
 
@@ -175,8 +182,11 @@ def roofline_block(classes, dtype, workload=None, timed=None):
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["traffic"] = None
     tr = measured_traffic(cls, workload)
+    roof["traffic"] = None
     if tr is not None:
-        roof["traffic"], roof["traffic_source"], roof["traffic_class"] = tr
+        # a PMC summary taken on ANOTHER build of the library is not this run's traffic: quoted under its own key, `traffic` stays null
+        roof["traffic_of_another_build" if tr[3] else "traffic"] = tr[0]
+        roof["traffic_source"], roof["traffic_class"] = tr[1], tr[2]
     roof["kernel"] = cls
     roof["avg_launch_ms"] = round(e["ms"] / max(e["launches"], 1), 4)
     roof["avg_launch_ms_alone"] = round(alone_ms, 4)
@@ -492,7 +502,7 @@ def main():
             "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_LABEL[c["dtype"]], "data": "synthetic",
-            "config": {"workload": c["name"], "per_gpu_batch": c["batch"], "global_batch": c["batch"] * world,
+            "config": {"workload": c["name"], "key": args.config, "per_gpu_batch": c["batch"], "global_batch": c["batch"] * world,
                        "height": c["H"], "width": c["W"], "storage_dtype": c["dtype"], "accumulate": "fp32",
                        "parallelism": f"dp{world}", "weights": "random-init (reference init, seed 123)",
                        "fwd_conv_gflop_per_img": round(fwd_flops_img / 1e9, 1),
@@ -510,8 +520,9 @@ def main():
             if full_classes:
                 schedule["serial_kernel_sum_ms"] = round(sum(e["ms"] for e in full_classes.values()), 3)
             ins = in_step_kernel_sum((args.config, c["batch"], DTYPE_LABEL[c["dtype"]]))
-            if ins is not None:
-                schedule["in_step_kernel_sum_ms"], schedule["in_step_source"] = ins
+            if ins is not None:   # (from a committed rocprofv3 summary; of another build of the library: under its own key)
+                schedule["in_step_kernel_sum_ms_of_another_build" if ins[2] else "in_step_kernel_sum_ms"] = ins[0]
+                schedule["in_step_source"] = ins[1]
             out["schedule"] = schedule
         if comm is not None:
             out["comm"] = comm

@@ -658,6 +658,13 @@ int dmm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 
 // ------------------------------------------------------------------------------------------------ single-kernel entry points
 namespace {
+// Descriptor upload of the single-kernel entry points.  The source is stack / local-vector memory of the call, so the copy must be
+// COMPLETE when this returns (an asynchronous copy from pageable memory only happens to be staged at once by the runtime), and what
+// the stream still runs may be reading the descriptors the scratch held before.
+hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  const hipError_t e = hipStreamSynchronize(st);
+  return e != hipSuccess ? e : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
 struct OneConv {
   int esz, SLOT, BK;
   int Ho, Wo, Hout, Wout, ostride, istride;
@@ -771,8 +778,8 @@ int dmm_conv_forward(const dmm_conv_desc* d, const void* x, const float* w, cons
   std::vector<int> prefix;
   PackDesc* dd; int* dp; int total_rows;
   layout_fwd(d, g, (uint8_t*)scratch, w, nullptr, packs, &dd, &dp, prefix, total_rows);
-  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(upload(dd, packs.data(), packs.size() * sizeof(PackDesc), st));
+  HIPCHK(upload(dp, prefix.data(), prefix.size() * sizeof(int), st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(launch_pack(dd, dp, (int)packs.size(), total_rows, d->dtype, st));
   if (stats) HIPCHK(hipMemsetAsync(stats, 0, 2 * d->Cout * sizeof(double), st));
@@ -836,8 +843,8 @@ int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, con
     if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
     HIPCHK(hipMemsetAsync(scratch, 0, S.off, st));
     int zero = 0;
-    HIPCHK(hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(dp, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(upload(dd, &pd, sizeof(pd), st));
+    HIPCHK(upload(dp, &zero, sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     WgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -872,8 +879,8 @@ int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, con
   float* zeros = (float*)S.take((size_t)rup(d->Cout, 8) * sizeof(float) + 64);
   if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
   HIPCHK(hipMemsetAsync(scratch, 0, S.off, st));
-  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(upload(dd, packs.data(), packs.size() * sizeof(PackDesc), st));
+  HIPCHK(upload(dp, prefix.data(), prefix.size() * sizeof(int), st));
   HIPCHK(hipStreamSynchronize(st));
   for (size_t ph = 0; ph < packs.size(); ++ph) {
     WgradArgs a;
@@ -918,8 +925,8 @@ static int build_dgrad(const dmm_conv_desc* d, const OneConv& g, const void* x, 
   if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
   int zero = 0;
   HIPCHK(hipMemsetAsync(zeros, 0, (size_t)rup(d->Cout, 8) * sizeof(float) + 64, st));
-  HIPCHK(hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(dp, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(upload(dd, &pd, sizeof(pd), st));
+  HIPCHK(upload(dp, &zero, sizeof(int), st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(launch_pack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, st));
   HIPCHK(hipMemsetAsync(red, 0, 2 * d->Cin * sizeof(double), st));
@@ -978,8 +985,8 @@ int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void
   PackDesc* dd; int* dp; int total_rows;
   const size_t used = layout_fwd(d, g, (uint8_t*)scratch, dw, dw, packs, &dd, &dp, prefix, total_rows);
   HIPCHK(hipMemsetAsync(scratch, 0, used, st));
-  HIPCHK(hipMemcpyAsync(dd, packs.data(), packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(dp, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(upload(dd, packs.data(), packs.size() * sizeof(PackDesc), st));
+  HIPCHK(upload(dp, prefix.data(), prefix.size() * sizeof(int), st));
   Scratch S{(uint8_t*)scratch, used};
   Bw1Args b;
   memset(&b, 0, sizeof(b));

@@ -608,6 +608,11 @@ hipError_t launch_conv3(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   if (cs == 0 && tspan == 6 && a.Npad != 64) return hipErrorNotSupported;
   const int pro = sg.scale ? 1 : (sg.q ? 2 : 0);
   if (epi == EPI_BNBWD && a.accumulate && a.out == nullptr) return hipErrorNotSupported;
+  // the final-gradient epilogue (eq / er) exists in ONE variant: the thin-only 5x5 data gradient, not accumulating, with an output
+  if ((a.eq != nullptr) != (a.er != nullptr)) return hipErrorNotSupported;
+  if (a.eq != nullptr && !(epi == EPI_BNBWD && cs == 0 && tspan == 4 && tstr == 1 && pro == 0 && a.out != nullptr && !a.accumulate &&
+                           a.red1 == nullptr && a.red2 == nullptr))
+    return hipErrorNotSupported;
   g.tiles_y = (a.Ho + C3_TH - 1) / C3_TH;
   g.tiles_x = (a.Wo + C3_TW - 1) / C3_TW;
   g.ntiles = a.B * g.tiles_y * g.tiles_x;

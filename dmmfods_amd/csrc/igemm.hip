@@ -792,6 +792,12 @@ extern template hipError_t launch_igemm_type<bf16>(const ConvArgs&, int, bool, h
 // The special-case families in dispatch order; `took` = the family that accepted the launch (IMPL_GENERIC: none did).
 static hipError_t dispatch_special(const ConvArgs& a, int dtype, int epi, hipStream_t st, int& took) {
   hipError_t e;
+  if (a.eq != nullptr || a.er != nullptr) {  // second pass of a two-pass BatchNorm backward: ONE kernel variant stores s*dz + q + r*x
+    took = IMPL_CONV3;                       // (conv3.hip's thin-only data gradient); every other family would silently store s*dz
+    if ((e = launch_conv3(a, dtype, epi, st)) != hipErrorNotSupported) return e;
+    took = IMPL_GENERIC;
+    return hipErrorNotSupported;
+  }
   took = IMPL_THIN;   // few output channels x many taps: gather once, reduce the taps in LDS
   if ((e = launch_thin_logits(a, dtype, epi, st)) != hipErrorNotSupported) return e;
   took = IMPL_HF;     // the head's first convolution, four parity phases in one launch: wave-specialised, phase weights resident in LDS
@@ -824,6 +830,10 @@ hipError_t launch_igemm(const ConvArgs& a, int dtype, int epi, bool mfma, hipStr
     if (e != hipErrorNotSupported) { note_impl(took); return e; }
   }
   note_impl(IMPL_GENERIC);
+  // what the generic kernels do not implement must fail here, not compute something else
+  if (a.eq != nullptr || a.er != nullptr) return hipErrorNotSupported;                      // the second pass of a two-pass BatchNorm backward
+  if (epi == EPI_BNBWD && a.out == nullptr && (a.pool2 || a.accumulate)) return hipErrorNotSupported;  // reductions-only: the plain prefetched path
+  if (a.nphase != 0) return hipErrorNotSupported;                                           // merged parity phases belong to conv3 / hf / cvp
   if (dtype == DT_F16) return launch_igemm_type<f16>(a, epi, mfma, st);
   if (dtype == DT_BF16) return launch_igemm_type<bf16>(a, epi, mfma, st);
   return launch_igemm_type<float>(a, epi, mfma, st);

@@ -931,14 +931,20 @@ struct Builder {
         // s*dz + q + r*x.  Traffic 2 x |x| + |g| instead of |x| + |g| (store) + 2 |g| + |x| (apply_corr).
         if (c3 && !raw && sb.matz && sb.q && !sb.ginit && !sb.materialized && c.nseg == 1 && c.R == 5 && c.S == 5 && dtype != DT_F32 &&
             !P.sw.no_two_pass) {
+          Op first_pass = o;                     // reductions only: stores nothing
+          first_pass.c.out = nullptr;
           second_pass = o;                       // stores; no reductions
           second_pass.c.red1 = nullptr; second_pass.c.red2 = nullptr;
           second_pass.c.eq = sb.q + sr.ch0; second_pass.c.er = sb.r + sr.ch0;
-          have_second = true;
-          second_buf = sr.buf;
-          a.out = nullptr;                       // first pass: reductions only
-          o.bytes = out_bytes(c) + srcb + w_bytes(c);          // reads dy and x, writes nothing
-          second_pass.bytes = out_bytes(c) + srcb * 2.0 + w_bytes(c);
+          // both MUTATED launches must still be conv3.hip's (the only kernel whose epilogue knows eq / er)
+          if (igemm_pick(first_pass.c, dtype, EPI_BNBWD, d.use_mfma != 0) == IMPL_CONV3 &&
+              igemm_pick(second_pass.c, dtype, EPI_BNBWD, d.use_mfma != 0) == IMPL_CONV3) {
+            have_second = true;
+            second_buf = sr.buf;
+            a.out = nullptr;
+            o.bytes = out_bytes(c) + srcb + w_bytes(c);          // reads dy and x, writes nothing
+            second_pass.bytes = out_bytes(c) + srcb * 2.0 + w_bytes(c);
+          }
         }
       }
       if (pending_w) {

@@ -80,7 +80,11 @@ def main():
         wb = 1024.0 * kw / nw if nw else None
         res[cls] = dict(launches_fetch_pass=nf, launches_write_pass=nw, read_bytes_per_launch=rd, write_bytes_per_launch=wb,
                         traffic_bytes_per_launch=(rd or 0) + (wb or 0))
-    json.dump(dict(config=a.config, batch=a.batch, dtype=a.dtype,
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.src_hash import source_hash
+    json.dump(dict(config=a.config, batch=a.batch, dtype=a.dtype, source_sha16=source_hash(),
                    method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB*1024; FETCH_SIZE x2 (gfx950)",
                    classes=res), open(a.out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * max(kv[1]["launches_fetch_pass"], 1)):

@@ -7,15 +7,22 @@ timeout -k 10 300 python3 bench.py --table --ops 2000 > $out/bench.json 2> $out/
 cat $out/bench.json
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- $B > $out/prof.log 2>&1 || exit 2
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-python3 - $out/kernel_stats.csv $out/kernel_stats.json <<'PY' || exit 2
-# the in-step kernel-time sum bench.py reports under "schedule": every dmm kernel of the 7 steps (5 timed + 2 warm-up) of the command
+python3 - $out/kernel_stats.csv $out/kernel_stats.json $out/prof.log <<'PY' || exit 2
+# the in-step kernel-time sum bench.py reports under "schedule": every dmm kernel of all steps (timed + warm-up) of the profiled command.
+# Workload, batch, dtype and step count come from the JSON line that very command printed; the source stamp ties the file to this build.
 import csv, json, sys
+sys.path.insert(0, ".")
+from tools.src_hash import source_hash
+line = json.loads([l for l in open(sys.argv[3]) if l.startswith("{") and '"metric"' in l][-1])
+steps = line["steps"] + line["warmup"]
+cfg = line["config"]
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "dmm" in r["Name"]]
 tot = sum(int(r["TotalDurationNs"]) for r in rows) / 1e6
-json.dump({"config": "c2", "batch": 4, "dtype": "f16", "steps": 7, "total_kernel_ms": round(tot, 3),
-           "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile",
-           "note": "all dmm:: kernels of both streams, 7 steps"}, open(sys.argv[2], "w"), indent=1)
-print("in-step kernel sum per step: %.2f ms" % (tot / 7))
+json.dump({"config": cfg["key"], "batch": cfg["per_gpu_batch"], "dtype": line["dtype"], "steps": steps, "total_kernel_ms": round(tot, 3),
+           "source_sha16": source_hash(), "workload": cfg["workload"],
+           "command": "rocprofv3 --kernel-trace --stats -- " + " ".join(sys.argv[4:]) if len(sys.argv) > 4 else "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile",
+           "note": "all dmm:: kernels of both streams, %d steps" % steps}, open(sys.argv[2], "w"), indent=1)
+print("in-step kernel sum per step: %.2f ms" % (tot / steps))
 PY
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o run -- $B > $out/pmcF.log 2>&1 || exit 3
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o run -- $B > $out/pmcW.log 2>&1 || exit 4
