@@ -147,6 +147,8 @@ struct WgradArgs {
   short ph_xtaps[4][4];   // taps of seg[0] per phase (ntaps each)
   short ph_ytap[4];       // parity tap of dy per phase
   float* ph_dpack[4];
+  // wgpw.hip: the taps of each phase of a multi-phase launch when they differ (the ConvTranspose's 1, 2, 2, 4); all 0 = seg[0].ntaps each
+  signed char ph_ntaps[4];
 };
 constexpr int W3_SLOT_FLOATS = 9 * 128 * 32;  // one workgroup's partial result of the dense 3x3 weight gradient (147 KB)
 constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at most (device-independent: plans are sized without a GPU)
@@ -155,7 +157,7 @@ constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at mos
 // wgrad_pick walk the dispatch without launching and honour the dmm_set_option switches of that moment) and the executor
 // dispatches from the recorded value, so a plan's labels, its profile classes and the kernels it runs cannot drift apart when an
 // option is toggled afterwards.  IMPL_AUTO (the single-kernel test entry points): decide at the call.
-enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG, IMPL_BW1, IMPL_HF, IMPL_CF, IMPL_COUNT };
+enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG, IMPL_BW1, IMPL_HF, IMPL_CF, IMPL_WGPW /* wgp in its wave-specialised form: noted beside IMPL_WGP */, IMPL_COUNT };
 struct LaunchCtl {
   bool dry = false;      // walk the eligibility tests, launch nothing
   int impl = IMPL_AUTO;  // the one family allowed to take the launch (IMPL_AUTO: every enabled family, in dispatch order)

@@ -813,14 +813,19 @@ struct Builder {
             (src_bytes(c) + ((ob.q && !ob.materialized && c.och0 + rup(c.N, 8) > ob.mat_front) ? 2.0 : 1.0) * out_bytes(c)) / np + w_bytes(c) * 4.0 / esz / np);
       }
     }
-    // Four phases with four taps each, all on wgp.hip (the head's 3x3 over the upsampled decoder output): ONE launch, the phases
-    // of a tile range side by side on one XCD - the half-resolution input (0.8 GB at C2) comes from HBM once instead of four times.
+    // Four phases, all on wgp.hip: ONE launch, the phases of a tile range side by side on one XCD - the input comes from HBM once
+    // instead of four times.  Round 4: the head's 3x3 over the upsampled decoder output (four taps in every phase; 0.8 GB of
+    // half-resolution input at C2).  Round 5: the decoder's ConvTranspose stages as well (1, 2, 2, 4 taps: WgradArgs::ph_ntaps; the
+    // wave-specialised form of the kernel, wgpw.hip, takes the phase's tap count per workgroup).
     if (!defer_scope && c.phases.size() == 4 && wseg == 1 && ops->size() >= 4 && !P.sw.no_wgp_merge) {
       const size_t first = ops->size() - 4;
-      bool ok = true;
+      bool ok = true, all4 = true;
       for (size_t k = first; k < ops->size(); ++k) {
         const Op& po = (*ops)[k];
-        ok = ok && po.kind == OP_WGRAD && po.impl == IMPL_WGP && po.w.nseg == 1 && po.w.seg[0].ntaps == 4 && po.leaf == (*ops)[first].leaf;
+        const int nt = po.w.seg[0].ntaps;
+        ok = ok && po.kind == OP_WGRAD && po.impl == IMPL_WGP && po.w.nseg == 1 && (nt == 1 || nt == 2 || nt == 4) && po.leaf == (*ops)[first].leaf &&
+             po.w.seg[0].src == (*ops)[first].w.seg[0].src && po.w.dy.src == (*ops)[first].w.dy.src;
+        all4 = all4 && nt == 4;
       }
       if (ok) {
         Op merged = (*ops)[first];
@@ -828,7 +833,8 @@ struct Builder {
         merged.flops = 0; merged.bytes = 0;
         for (int ph = 0; ph < 4; ++ph) {
           const Op& po = (*ops)[first + ph];
-          for (int t = 0; t < 4; ++t) merged.w.ph_xtaps[ph][t] = po.w.seg[0].taps[t];
+          for (int t = 0; t < 4; ++t) merged.w.ph_xtaps[ph][t] = po.w.seg[0].taps[t < po.w.seg[0].ntaps ? t : 0];
+          merged.w.ph_ntaps[ph] = all4 ? 0 : (signed char)po.w.seg[0].ntaps;
           merged.w.ph_ytap[ph] = po.w.dy.taps[0];
           merged.w.ph_dpack[ph] = po.w.dpack;
           merged.flops += po.flops; merged.bytes += po.bytes;

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void wgp_kernel(const WgpArgs g) {
 
 static bool g_wgp = !lab_flag("DMM_NO_WGP");
 void wgp_set_enabled(bool on) { g_wgp = on; }
+// the wave-specialised form (wgpw.hip)
+hipError_t launch_wgpw(const WgradArgs& a, int dtype, int ntap, int nj, int tiles_y, int tiles_x, int ntiles, int tiles_per_wg, int nsplit, int nct,
+                       int ncot, int dymin, int dxmin, const int* ph_dymin, const int* ph_dxmin, int nwg, hipStream_t st);
 
 
 template <typename T, int NTAP, int NJ, int PQ>
@@ -285,7 +288,10 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
     fprintf(stderr, "wgp? nseg %d x: mode %d istride %d Hs %d Ws %d (Ho %d Wo %d) scale %d C %d Cpad %d ntaps %d | y: mode %d ntaps %d istride %d Hs %d Ws %d C %d | N %d Npad %d\n",
             a.nseg, x.mode, x.istride, x.Hs, x.Ws, a.Ho, a.Wo, x.scale != nullptr, x.C, x.Cpad, x.ntaps, y.mode, y.ntaps, y.istride, y.Hs, y.Ws, y.C, a.N, a.Npad);
   if (x.mode != G_PLAIN || x.istride != 1 || x.Hs != a.Ho || x.Ws != a.Wo || x.scale == nullptr || x.C % WP_CA || x.Cpad != x.C) return hipErrorNotSupported;
-  if (x.ntaps != 2 && x.ntaps != 4) return hipErrorNotSupported;
+  static const bool ws = !lab_flag("DMM_NO_WGPW");   // wave-specialised form (wgpw.hip) for the materialised output gradient
+  // one tap: only the (0, 0) parity phase of a ConvTranspose (stride-2 gradient rows), and only in the wave-specialised form
+  if (x.ntaps == 1 && !(ws && y.istride == 2 && y.q == nullptr && (a.nphase == 0 || a.nphase == 4) && a.nseg == 1)) return hipErrorNotSupported;
+  if (x.ntaps != 1 && x.ntaps != 2 && x.ntaps != 4) return hipErrorNotSupported;
   if (a.nseg == 2 && !(a.seg[1].C == 8 && a.seg[1].nchunks >= 1)) return hipErrorNotSupported;
   if (y.mode != G_PLAIN || y.ntaps != 1 || y.scale != nullptr || (y.istride != 1 && y.istride != 2)) return hipErrorNotSupported;
   if (y.Hs != a.Ho * y.istride || y.Ws != a.Wo * y.istride) return hipErrorNotSupported;
@@ -293,16 +299,22 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   if (a.nphase < 0 || a.nphase > 4 || (a.nphase > 0 && a.nseg != 1)) return hipErrorNotSupported;
   int dymin = 127, dxmin = 127;
   int ph_dymin[4] = {0, 0, 0, 0}, ph_dxmin[4] = {0, 0, 0, 0};
+  // a multi-phase launch whose phases differ in their tap counts (the ConvTranspose's 1, 2, 2, 4: WgradArgs::ph_ntaps): wgpw.hip only
+  bool mixed = false;
+  for (int ph = 0; ph < a.nphase; ++ph) mixed = mixed || (a.ph_ntaps[ph] != 0 && a.ph_ntaps[ph] != x.ntaps);
+  if (mixed && !(ws && y.q == nullptr && a.nphase == 4 && y.istride == 2)) return hipErrorNotSupported;
   for (int ph = 0; ph < std::max(1, a.nphase); ++ph) {   // every phase: taps inside a 2x2 box, each offset once; parity inside the stride
     const short* taps = a.nphase > 0 ? a.ph_xtaps[ph] : x.taps;
+    const int pnt = (a.nphase > 0 && a.ph_ntaps[ph] != 0) ? a.ph_ntaps[ph] : x.ntaps;
+    if (pnt != 1 && pnt != 2 && pnt != 4) return hipErrorNotSupported;
     int ymin = 127, xmin = 127, ymax = -128, xmax = -128;
     bool seen[4] = {false, false, false, false};
-    for (int t = 0; t < x.ntaps; ++t) {
+    for (int t = 0; t < pnt; ++t) {
       const int dy = (int)(signed char)(taps[t] & 0xff), dx = (int)(signed char)((taps[t] >> 8) & 0xff);
       ymin = std::min(ymin, dy); ymax = std::max(ymax, dy); xmin = std::min(xmin, dx); xmax = std::max(xmax, dx);
     }
     if (ymax - ymin > 1 || xmax - xmin > 1) return hipErrorNotSupported;
-    for (int t = 0; t < x.ntaps; ++t) {
+    for (int t = 0; t < pnt; ++t) {
       const int dy = (int)(signed char)(taps[t] & 0xff) - ymin, dx = (int)(signed char)((taps[t] >> 8) & 0xff) - xmin;
       if (seen[dy * 2 + dx]) return hipErrorNotSupported;
       seen[dy * 2 + dx] = true;
@@ -315,7 +327,7 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
     if (ph == 0) { dymin = ymin; dxmin = xmin; }
   }
   const int ntap = x.ntaps;
-  const int nj = (ntap == 2 && a.N % 128 == 0) ? 4 : 2;
+  const int nj = (ntap <= 2 && a.N % 128 == 0 && a.nphase == 0) ? 4 : 2;   // (multi-phase launches: 64 output channels per workgroup in every phase)
   if (g_ctl.dry) return hipSuccess;
   WgpArgs g;
   g.w = a;
@@ -340,6 +352,11 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
   const int units = g.nsplit * pairs;
   const int nwg = a.nphase > 0 ? ((units + 7) / 8) * 8 * nph : units;
   const int pq = y.q ? 2 : 0;
+  if (ws && pq == 0) {
+    note_impl(IMPL_WGPW);   // (beside IMPL_WGP, which the dispatcher notes: the family is wgp, this says which form ran)
+    return launch_wgpw(a, dtype, ntap, nj, g.tiles_y, g.tiles_x, g.ntiles, g.tiles_per_wg, g.nsplit, g.nct, g.ncot, dymin, dxmin, ph_dymin, ph_dxmin,
+                       nwg, st);
+  }
   if (trace) fprintf(stderr, "wgp: ntap %d nj %d pq %d pairs %d nsplit %d tiles/wg %d\n", ntap, nj, pq, pairs, g.nsplit, g.tiles_per_wg);
   return dtype == DT_F16 ? launch_wgp_type<f16>(g, ntap, nj, pq, nwg, st) : launch_wgp_type<bf16>(g, ntap, nj, pq, nwg, st);
 }

@@ -70,6 +70,19 @@ def test_parity_phase_weight_gradients_with_deferred_correction(lab, dtype):
         assert lab.backward_case(f"convT {Ci}->{Co}", dtype, B, H, W, Ci, Co, 3, 3, 1, transposed=1, with_q=1, what="wgrad", expect="wgp")
 
 
+@pytest.mark.parametrize("dtype", [1, 2], ids=["fp16", "bf16"])
+def test_parity_phase_weight_gradients_wave_specialised(lab, dtype):
+    """Round 5: wgpw.hip - wgp.hip's tiles run by eight waves (four matrix waves on the accumulators, four loader waves with two
+    register sets of inline-assembly loads, two LDS image sets, one raw barrier per tile) for the MATERIALISED output gradient, which
+    is what every launch of the benchmarked plans feeds it; now also the ConvTranspose's one-tap (0, 0) phase.  Against fp32 torch
+    autograd of conv_transpose2d on the same 16-bit-rounded operands: 64 and 128-column result tiles (NJ = 2 / 4), one and several
+    128-channel input tiles, ragged 8 x 16 pixel tiles, fewer tiles than workgroups, an odd number of tiles per workgroup."""
+    for (B, H, W, Ci, Co) in [(2, 12, 20, 128, 64), (1, 9, 17, 256, 128), (1, 8, 16, 128, 128), (3, 5, 3, 128, 64), (1, 24, 40, 256, 64)]:
+        assert lab.backward_case(f"convT {Ci}->{Co} {B}x{H}x{W}", dtype, B, H, W, Ci, Co, 3, 3, 1, transposed=1, with_q=0, what="wgrad", expect="wgpw")
+    # with the deferred correction on the gradient the four-wave kernel keeps the launch
+    assert lab.backward_case("convT 128->64 q", dtype, 2, 12, 20, 128, 64, 3, 3, 1, transposed=1, with_q=1, what="wgrad", expect="wgp")
+
+
 PRODUCTION = [  # name, B, H, W, Cin, Cout, R, stride, pad, bn, transposed, family: the launches of BASELINE configs[1] (C2) that run on LDS pipelines
     ("stem 7x7s2 8->64 @1280x1920", 4, 1280, 1920, 8, 64, 7, 2, 3, 0, 0, "conv3"),
     ("dense 3x3 128->32 @320x480", 4, 320, 480, 128, 32, 3, 1, 1, 1, 0, "cf"),      # large maps: the wave-specialised kernel (cf.hip, round 4)
@@ -104,6 +117,10 @@ def test_backward_kernels_at_production_size(lab, dtype):
         assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, what="wgradT", ref_dev="cuda", expect="wg3")
         assert lab.backward_case(f"3x3 128->32 @{H}x{W}", dtype, B, H, W, 128, 32, 3, 3, 1, with_q=1, acc=1, what="dgrad", ref_dev="cuda", expect="conv3")
     assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=1, what="wgrad", ref_dev="cuda", expect="wgp")
+    # round 5: the wave-specialised form (materialised gradient) with the chip full: the decoder's second and last stages
+    assert lab.backward_case("convT 256->256 @160x240 ws", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=0, what="wgrad", ref_dev="cuda", expect="wgpw")
+    assert lab.backward_case("convT 128->128 @320x480 ws", dtype, B, 320, 480, 128, 128, 3, 3, 1, transposed=1, with_q=0, what="wgrad", ref_dev="cuda", expect="wgpw")
+    assert lab.backward_case("convT 512->512 @80x120 ws", dtype, B, 80, 120, 512, 512, 3, 3, 1, transposed=1, with_q=0, what="wgrad", ref_dev="cuda", expect="wgpw")
     assert lab.backward_case("convT 256->256 @160x240", dtype, B, 160, 240, 256, 256, 3, 3, 1, transposed=1, with_q=0, what="dgrad", ref_dev="cuda", expect="cvp")
     # round 4: the head's kernels with the chip full - the stride-2 data gradient towards the decoder (cvd<64, true>: the
     # 3x3 over the nearest-x2 upsampled map, four sub-grids of merged taps) and the 8-channel weight gradients (wg5: the 5x5 onto the
@@ -378,6 +395,44 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
     k = "dec_out_to_heat_maps.refine0.weight"
     assert float(grads[1][k].abs().max()) > 0
     assert _rel(grads[0][k], grads[1][k]) < tol, _rel(grads[0][k], grads[1][k])
+    for k2 in grads[0]:
+        assert _rel(grads[0][k2], grads[1][k2]) < 2e-3, k2
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_decoder_weight_gradient_phases_in_one_launch(dtype, monkeypatch):
+    """Round 5: the four output-parity phases of a decoder ConvTranspose's weight gradient (1, 2, 2 and 4 taps) run as ONE launch of the
+    wave-specialised kernel (wgpw.hip: the phase's tap count is taken per workgroup, 64 output channels per workgroup in every phase,
+    the four phases of a tile range side by side on one XCD).  Round 4 ran them as three wgp launches and one generic launch, each
+    sweeping the stage's input.  densenet121 widths (1024 / 512 / 256 / 128 decoder channels: several input and output channel tiles).
+    Against four launches (DMM_NO_WGP_MERGE=1) every ConvTranspose weight gradient agrees to the order of the fp32 atomics, and so
+    does every other gradient; the merged list holds ONE wgp launch per decoder stage (and the head's)."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=14))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=5))
+    grads, nl = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
+        model.close()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labels = plan_labels(model._last[0], lists=(1,))
+        nl[off] = sum(lab.startswith("wgp.") and "/d.TC_" in lab for lab in labels)
+        grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
+    model.close()
+    assert (nl[0], nl[1]) == (4, 16), nl
+    for j in range(1, 5):
+        k = f"decoder.Transposed_Convolution_{j}.weight"
+        assert float(grads[1][k].abs().max()) > 0
+        assert _rel(grads[0][k], grads[1][k]) < 1e-3, (k, _rel(grads[0][k], grads[1][k]))
     for k2 in grads[0]:
         assert _rel(grads[0][k2], grads[1][k2]) < 2e-3, k2
 
