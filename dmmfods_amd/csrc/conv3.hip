@@ -274,7 +274,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
     const int y = y0 + tid / C3_TW, x = x0 + tid % C3_TW;
     rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y * a.ostride + opy) * a.Wout + x * a.ostride + opx : -1;
   }
-  if (tid < 2 * BN) red[tid] = 0.0;
+  // (forward: the BatchNorm sums of ALL tiles of the walk gather in `red`, zeroed in front of the first; data gradients: one tile per workgroup)
+  if (tid < 2 * BN && lt == (int)blockIdx.x) red[tid] = 0.0;
 
   // ---- epilogue operands of the fused BN/ReLU backward: x at every output position, issued now, used after the K loop ----
   if constexpr (EPI == EPI_BNBWD) {
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
       if (pix < 0 || !colvalid) continue;
       *(V*)(out + (size_t)pix * a.ldo + n) = *(const V*)(Cs + row * CPITCH + cv * SLOT);
     }
+    // (round 5: gathered over the walk in LDS - thread tid owns red[tid] -, one round of global atomics behind the loop)
     if (!(a.stat_sum == nullptr || (C3_DBG & 32)))
     if (!(C3_DBG & 16) && tid < 2 * BN) {
       const int col = tid % BN, which = tid / BN;
@@ -429,8 +431,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += (double)wpart[(w * 2 + which) * BN + col];
-        const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
-        atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + col, s);
+        red[tid] += s;
       }
     }
   } else {  // EPI_BNBWD: acc = d(relu(bn(x))); mask, reduce, scatter s*dz (see igemm.hip)
@@ -489,6 +490,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3_kernel(const Conv3Args g) {
   if constexpr (PERSIST && C3_RAW_EPI_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else __syncthreads();
   }  // (tile loop)
+  if constexpr (EPI == EPI_STORE) {
+    if (!(a.stat_sum == nullptr || (C3_DBG & (16 | 32))) && tid < 2 * BN) {   // (red[tid] was written by this very thread)
+      const int col = tid % BN, which = tid / BN;
+      if (col < a.N) {
+        const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+        atomic_add_f64((which ? a.stat_sq : a.stat_sum) + rep + col, red[tid]);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
