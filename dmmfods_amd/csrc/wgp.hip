@@ -289,8 +289,12 @@ hipError_t launch_wgp(const WgradArgs& a, int dtype, hipStream_t st) {
             a.nseg, x.mode, x.istride, x.Hs, x.Ws, a.Ho, a.Wo, x.scale != nullptr, x.C, x.Cpad, x.ntaps, y.mode, y.ntaps, y.istride, y.Hs, y.Ws, y.C, a.N, a.Npad);
   if (x.mode != G_PLAIN || x.istride != 1 || x.Hs != a.Ho || x.Ws != a.Wo || x.scale == nullptr || x.C % WP_CA || x.Cpad != x.C) return hipErrorNotSupported;
   static const bool ws = !lab_flag("DMM_NO_WGPW");   // wave-specialised form (wgpw.hip) for the materialised output gradient
-  // one tap: only the (0, 0) parity phase of a ConvTranspose (stride-2 gradient rows), and only in the wave-specialised form
-  if (x.ntaps == 1 && !(ws && y.istride == 2 && y.q == nullptr && (a.nphase == 0 || a.nphase == 4) && a.nseg == 1)) return hipErrorNotSupported;
+  // one tap: the (0, 0) parity phase of a ConvTranspose (stride-2 gradient rows) and the decoder's plain 1x1 convolutions conv_reduce
+  // (reference M:150-153; C_in = 1024 ... 256 -> C_in / 2 at the block resolutions), only in the wave-specialised form.  (The dense layers'
+  // 128-wide bottlenecks never come here: bw1.hip fuses their weight gradient with the data gradient.)
+  static const bool ws1x1 = lab_flag("DMM_WGPW_1X1");   // measured (round 5): 0.198 / 0.192 / 0.066 ms against the generic kernel's 0.178 / 0.171 / 0.064: off
+  if (x.ntaps == 1 && !(ws && (y.istride == 2 || (ws1x1 && y.istride == 1 && x.taps[0] == 0)) && y.q == nullptr && (a.nphase == 0 || a.nphase == 4) && a.nseg == 1))
+    return hipErrorNotSupported;
   if (x.ntaps != 1 && x.ntaps != 2 && x.ntaps != 4) return hipErrorNotSupported;
   if (a.nseg == 2 && !(a.seg[1].C == 8 && a.seg[1].nchunks >= 1)) return hipErrorNotSupported;
   if (y.mode != G_PLAIN || y.ntaps != 1 || y.scale != nullptr || (y.istride != 1 && y.istride != 2)) return hipErrorNotSupported;

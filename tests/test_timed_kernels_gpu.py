@@ -174,6 +174,7 @@ def _rel(a, b):
 def _errors(model, logits, met, emu, g_emu, o64, g64):
     num = den = ynum = 0.0
     worst = (0.0, None)
+    per = {}
     for k, p in model.named_parameters():
         got = p.grad.detach().cpu().double()
         num += float((got - g_emu[k]).pow(2).sum())
@@ -182,7 +183,8 @@ def _errors(model, logits, met, emu, g_emu, o64, g64):
         if p.dim() == 4:  # convolution weights, per tensor: rel L2 against the emulation
             e = float((got - g_emu[k]).norm() / g_emu[k].norm().clamp_min(1e-30))
             worst = max(worst, (e, k))
-    return dict(logits=_rel(logits.detach(), emu["logits"]), y_logits=_rel(emu["logits"], o64["logits"]),
+            per[k] = e
+    return dict(per_conv=per, logits=_rel(logits.detach(), emu["logits"]), y_logits=_rel(emu["logits"], o64["logits"]),
                 loss=_rel(met["loss_per_class"], emu["loss_per_class"]),
                 grads=(num / den) ** 0.5, y_grads=(ynum / den) ** 0.5, worst_conv=worst)
 
@@ -214,14 +216,26 @@ def test_c2_c3_networks_fp16_against_oracle_emulation(variant, H, W):
     e = _errors(model, logits, met, emu, g_emu, o64, g64)
     print(f"d121 {variant} {H}x{W} fp16: logits {e['logits']:.3e} (emulation vs fp64 {e['y_logits']:.3e}), loss {e['loss']:.3e}, "
           f"grads rel L2 {e['grads']:.3e} (emulation vs fp64 {e['y_grads']:.3e}), worst conv tensor {e['worst_conv'][0]:.3e} {e['worst_conv'][1]}")
+    top = sorted(e["per_conv"].items(), key=lambda kv: -kv[1])[:4]
+    print("   worst conv tensors: " + ", ".join(f"{k} {v:.3f}" for k, v in top))
+    other = sorted(((k, v) for k, v in e["per_conv"].items() if "denselayer" not in k), key=lambda kv: -kv[1])
+    print("   outside the dense layers: " + ", ".join(f"{k} {v:.3f}" for k, v in other))
     assert torch.isfinite(logits).all() and torch.isfinite(model.grad_arena).all()
     assert e["loss"] < 5e-3, e
     assert e["logits"] < max(2e-2, 1.0 * e["y_logits"]), e      # the HIP path is closer to the emulation than the emulation to fp64
     assert e["grads"] < max(5e-2, 1.0 * e["y_grads"]), e
-    # per tensor (round 4): at this depth single tensors are noise-dominated on either side - measured worst 0.35 ... 0.55
-    # (a 1x1 or 3x3 weight of blocks 1 / 4, a different one per size) - so the bound only catches a tensor that is plainly wrong;
-    # the sharp per-tensor bounds are the two-block net's below
-    assert e["worst_conv"][0] < 0.8, e["worst_conv"]
+    # Per tensor (round 5).  16-bit storage noise ACCUMULATES on the way back from the loss: measured (MI355X,
+    # this test, four cases) refine1 0.000, refine0 0.016 ... 0.039, the last ConvTranspose 0.026 ... 0.064, then +0.03 ... 0.05 per
+    # decoder stage up to 0.27 ... 0.33 at the first one and 0.31 ... 0.41 in the encoder's stem / transitions; the dense layers'
+    # conv1 / conv2 weights - noise-dominated on either side: two correct summation orders differ by 20 % there - 0.35 ... 0.55.  So the
+    # bound is per group, 1.5 x the worst measured of the group, and SHARP on the tensors the head's and the last decoder stage's kernels
+    # produce directly (hf / wgp.n64 merged, cvp_multi / cvd / wgp.n128 merged, thin / wg5): a wrong tap, phase or channel mapping in any
+    # of them is an O(1) error in exactly these.
+    sharp = {"dec_out_to_heat_maps.refine1.weight": 1e-3, "dec_out_to_heat_maps.refine0.weight": 0.06, "decoder.Transposed_Convolution_4.weight": 0.10}
+    dense_bound = 1.5 * {("early", 64): 0.378, ("early", 128): 0.346, ("mid3", 64): 0.553, ("mid3", 128): 0.395}[(variant, H)]
+    for k, v in e["per_conv"].items():
+        bound = sharp.get(k) or (dense_bound if "denselayer" in k else (0.5 if k.startswith("decoder.") else 0.62))
+        assert v < bound, (k, v, bound)
 
 
 # ------------------------------------------------------------------------------------------------ (3) bf16 at layer depth
@@ -248,8 +262,22 @@ def test_two_block_net_layer_level_16bit(dtype, storage, tol_log, tol_g):
     e = _errors(model, logits, met, emu, g_emu, o64, g64)
     print(f"two-block net {dtype}: logits {e['logits']:.3e} (emulation vs fp64 {e['y_logits']:.3e}), loss {e['loss']:.3e}, "
           f"grads rel L2 {e['grads']:.3e} (emulation vs fp64 {e['y_grads']:.3e}), worst conv tensor {e['worst_conv'][0]:.3e} {e['worst_conv'][1]}")
+    print("   per conv tensor: " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(e["per_conv"].items(), key=lambda kv: -kv[1])))
+    print("   families: " + " ".join(sorted({lab.split("/")[0] for lab in labels})))
     assert e["logits"] < tol_log and e["loss"] < tol_log and e["grads"] < tol_g, e
     assert e["worst_conv"][0] < {"fp16": 0.15, "bf16": 0.4}[dtype], e["worst_conv"]   # measured 0.070 / 0.199 (block 2's conv1.weight)
+    # Round 5: this net's last decoder stage (128 -> 128 channels) and head have the DenseNet-121 widths, so
+    # the merged / wave-specialised launches are all in its list - hf.store (head forward), cvp.store with the four phases in one
+    # launch, cvp.bnbwd, wgp.n128 (wgpw.hip, the ConvTranspose's four phases in one launch), wgp.n64 (the head's) - seven BatchNorms
+    # away from the loss at most.  Per tensor against the emulation, bounds = 2 x measured (fp16 / bf16): refine1 0.0000 / 0.0003,
+    # refine0 0.0141 / 0.0384, the last ConvTranspose 0.0207 / 0.0596, its conv_reduce 0.046 / 0.138.
+    for fam in ("hf.store", "cvp.store", "cvp.bnbwd", "wgp.n128", "wgp.n64", "pig.store"):
+        assert any(lab.startswith(fam) for lab in labels), fam
+    assert sum(lab.startswith("cvp.store") for lab in labels) == 2 and sum(lab.startswith("wgp.n128") for lab in labels) == 1, "the phases are not merged"
+    named = {"dec_out_to_heat_maps.refine1.weight": (1e-3, 1e-3), "dec_out_to_heat_maps.refine0.weight": (0.03, 0.08),
+             "decoder.Transposed_Convolution_2.weight": (0.042, 0.12), "decoder.Transposed_Convolution_Sequence_2.conv_reduce.weight": (0.093, 0.28)}
+    for k, (b16, bbf) in named.items():
+        assert e["per_conv"][k] < (b16 if dtype == "fp16" else bbf), (k, e["per_conv"][k])
 
 
 # ------------------------------------------------------------------------------------------------ (4) the compact effective gradient
