@@ -355,6 +355,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_WGRAD: e = launch_wgrad(o.w, dt, mfma, lst, o.impl); break;
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
       case OP_BW1RED: e = launch_bw1_reduce(o.b1, lst); break;
+      case OP_RAWFIN: e = launch_wg5_rawfin(o.rf, lst); break;
       case OP_JOIN: if (o.epi == 1) join_pack(); else join_side(); break;  // the main stream waits for what the side (epi 1: pack) stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;

@@ -147,9 +147,28 @@ struct WgradArgs {
   short ph_xtaps[4][4];   // taps of seg[0] per phase (ntaps each)
   short ph_ytap[4];       // parity tap of dy per phase
   float* ph_dpack[4];
+  // wg5.hip, PY = 2 (round 5): the thin operand enters as the two factors of its activation - batch mean / inverse std of its
+  // BatchNorm (scale / shift: seg[0]) - and the factor correlations go to sbuf [5][64][32] instead of dpack (nullable: off)
+  const float* t_mean;
+  const float* t_invstd;
+  float* sbuf;
   // wgpw.hip: the taps of each phase of a multi-phase launch when they differ (the ConvTranspose's 1, 2, 2, 4); all 0 = seg[0].ntaps each
   signed char ph_ntaps[4];
 };
+// wg5_rawfin_kernel (wg5.hip): see there
+struct RawFinArgs {
+  const float* sbuf;     // [5][64][32] factor correlations
+  float* dpack;          // packed gradient of the raw-input segment [3][Npad][32]
+  int Npad;
+  const float* w;        // master weights [64][Kin][9]
+  int Kin, koff, nreal;  // input channels of the convolution, first raw-input channel, real raw-input channels (<= 8)
+  int tapw[9];           // master tap of packed tap t
+  const float* gamma;    // of the raw-input channels (8 readable)
+  const float* beta;
+  double* red1;          // BatchNorm-backward reductions of the raw-input channels, replica 0
+  double* red2;
+};
+constexpr int W5_SBUF_FLOATS = 5 * 64 * 32;
 constexpr int W3_SLOT_FLOATS = 9 * 128 * 32;  // one workgroup's partial result of the dense 3x3 weight gradient (147 KB)
 constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at most (device-independent: plans are sized without a GPU)
 

@@ -751,6 +751,7 @@ struct Builder {
     bool wt_deferred = false;
     Op wt_op;
     bool have_second = false;
+    bool raw_stats = false;   // (round 5) the raw-input channels' BatchNorm sums come from the weight gradient: no data gradient towards them
     Op second_pass;
     int second_buf = -1;
     if (c.wgrad_transposed && dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.nseg == 1 && c.seg[0].C == 128 &&
@@ -845,6 +846,12 @@ struct Builder {
         }
       }
     }
+    // Round 5: with the raw-input segment's weight gradient on wg5.hip, that launch correlates the output gradient with the two FACTORS
+    // of the activation (wg5.hip, PY = 2) and a one-workgroup launch turns the result into the packed weight gradient AND the
+    // BatchNorm-backward sums of the raw-input channels - the reductions-only data gradient towards the raw input (a leaf launch: one
+    // more pass over the full-resolution gradient, 0.69 ms at C2) is not emitted.  The buffer is reserved by shape alone.
+    float* raw_sbuf = nullptr;
+    if (raw_once && dtype != DT_F32 && c.N == 64 && !P.sw.no_raw_stats) raw_sbuf = zbptr<float>(W5_SBUF_FLOATS);
     if (raw_once) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;
@@ -860,9 +867,31 @@ struct Builder {
       a.dpack = (float*)pd.dpack + (size_t)pd.seg[0].nchunks * pd.Npad * BK;   // behind segment 0's chunks
       char cb[32];
       o.impl = wgrad_pick(a, dtype, d.use_mfma != 0);
+      if (raw_sbuf != nullptr && o.impl == IMPL_WG5 && c.seg[1].bn >= 0 && !defer_scope) {   // (a held-back launch would run behind its finish)
+        WgradArgs f = a;
+        f.sbuf = raw_sbuf;
+        f.t_mean = bns[c.seg[1].bn].mean + c.seg[1].bn_c0;
+        f.t_invstd = bns[c.seg[1].bn].invstd + c.seg[1].bn_c0;
+        if (wgrad_pick(f, dtype, d.use_mfma != 0) == IMPL_WG5) { a = f; raw_stats = true; }
+      }
       const Buf& rb = bufs[c.seg[1].buf];
       tag(o, ncls(o.impl == IMPL_WG5 ? "wg5" : "wgrad", pd.Npad, cb), short_name(c.wname) + ".raw", conv_flops(c, 1) * ((double)c.seg[1].Cw / c.Kin),
           (double)rb.B * rb.H * rb.W * 8 * esz + ((ob.q && !ob.materialized) ? 2.0 : 1.0) * out_bytes(c));
+      if (raw_stats) {   // right behind it on the same stream: packed gradient of the segment + the norm's sums for these channels
+        const WgradArgs wa = o.w;
+        const bool leaf_of = o.leaf;
+        Op& fo = push(OP_RAWFIN);
+        fo.leaf = leaf_of ? leaf_of : 1;
+        RawFinArgs& r = fo.rf;
+        memset(&r, 0, sizeof(r));
+        r.sbuf = wa.sbuf; r.dpack = wa.dpack; r.Npad = wa.Npad;
+        r.w = Pp + T(c.wname).off; r.Kin = c.Kin; r.koff = c.seg[1].koff; r.nreal = c.seg[1].Cw;
+        for (int t = 0; t < 9; ++t) r.tapw[t] = (int)(pd.seg[1].tapw[t] & 0xff);
+        const Bn& bn = bns[c.seg[1].bn];
+        r.gamma = bn.gamma + c.seg[1].bn_c0; r.beta = bn.beta + c.seg[1].bn_c0;
+        r.red1 = bn.red1 + c.seg[1].bn_c0; r.red2 = bn.red2 + c.seg[1].bn_c0;
+        tag(fo, "wg5.rawfin", short_name(c.wname) + ".raw", 0, W5_SBUF_FLOATS * 4.0);
+      }
     }
     }
     // A dense layer's 1x1 bottleneck convolution: its weight gradient and its data gradient read the same three tensors; when the
@@ -880,6 +909,7 @@ struct Builder {
     for (int s = 0; s < c.nseg; ++s) {
       SegRec& sr = c.seg[s];
       if (sr.dgrad == DG_NONE) continue;
+      if (raw_stats && s == 1 && is_raw_input(sr.buf)) continue;   // its only purpose were the two sums wg5.rawfin has just produced
       Buf& sb = bufs[sr.buf];
       std::vector<Tap> taps;
       int istride = 1, rB = sb.B, rH = sb.H, rW = sb.W, pool2 = 0, ostride = 1;
@@ -1662,6 +1692,7 @@ PlanSwitches PlanSwitches::from_environment() {
   s.no_eff_compact = on("DMM_NO_EFF_COMPACT");
   s.no_s2_interleave = on("DMM_NO_S2_INTERLEAVE");
   s.defer_wgrad = on("DMM_DEFER_WGRAD");
+  s.no_raw_stats = on("DMM_NO_RAW_STATS");
   const char* pc = getenv("DMM_PACK_CUT");
   s.pack_cut = pc ? std::max(1, atoi(pc)) : 0;
   return s;

@@ -37,7 +37,7 @@ void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK);
 void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK);
 
 enum OpKind { OP_MEMSET = 0, OP_CONVERT, OP_IGEMM, OP_WGRAD, OP_BNFIN, OP_BNBWD, OP_POOL, OP_POOLBWD, OP_BCE, OP_PACK, OP_UNPACK,
-              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN, OP_BW1RED };
+              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN, OP_BW1RED, OP_RAWFIN };
 
 struct MemsetArgs { void* p; size_t bytes; };
 struct CopyArgs { void* dst; const void* src; size_t bytes; };
@@ -70,6 +70,7 @@ struct Op {
     PackArgs pk;
     ApplyCorrArgs ac;
     Bw1Args b1;
+    RawFinArgs rf;
   };
   Op() : kind(0), epi(0), leaf(0), signal(-1), impl(IMPL_AUTO), flops(0), bytes(0) { label[0] = 0; }
 };
@@ -98,11 +99,13 @@ struct GradBucket {
 //   DMM_NO_S2_INTERLEAVE=1  mid fusion: the second encoder's launch records behind the first's instead of alternating
 //   DMM_PACK_CUT=<n>        the forward record in front of which the late layers' weight pack is joined (1 = behind the stem)
 //   DMM_DEFER_WGRAD=1       the head's / decoder's multi-tap weight gradients held back until backward reaches the encoder
+//   DMM_NO_RAW_STATS=1      the BatchNorm-backward sums of the head's raw-input channels from a data-gradient pass of their own
+//                           (round 4) instead of from the weight gradient's factor correlations (wg5.hip, PY = 2)
 // Process-wide (capi.cpp, read when the library is loaded; also dmm_set_option): DMM_NO_OVERLAP, DMM_GRAPH, DMM_GRAD_BUCKET_MB;
 // diagnostics: DMM_TRACE_DESTROY.  Everything else that used to be an environment switch is a compile-time lab knob (common.h).
 struct PlanSwitches {
   bool no_pack_tiles = false, no_hf = false, no_c3_merge = false, no_cvp_merge = false, no_wgp_merge = false, no_two_pass = false,
-       no_eff_compact = false, no_s2_interleave = false, defer_wgrad = false;
+       no_eff_compact = false, no_s2_interleave = false, defer_wgrad = false, no_raw_stats = false;
   int pack_cut = 0;  // 0: by weight count
   static PlanSwitches from_environment();
 };

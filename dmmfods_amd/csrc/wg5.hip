@@ -23,13 +23,15 @@ constexpr int W5_CA = 64;
 constexpr int W5_A_BYTES = BM * W5_CA * 2;                    // 16 KB, 128-byte rows, 64-byte granule XOR-ed with (row >> 1) & 1
 // TR = tap radius, STR = source stride of the thin operand: (5x5, stride 1) = the head's last convolution; (7x7, stride 2) = the
 // stem convolution conv0 (reference M:47-52 / torchvision features.conv0), whose thin operand is the raw input.
-template <int TR, int STR>
+// TCOL = columns per tap: 8 (the thin operand's eight channels) or 16 (PY == 2: two variants of each channel, see below)
+template <int TR, int STR, int TCOL = 8>
 struct W5Geo {
   static constexpr int NT = (2 * TR + 1) * (2 * TR + 1);        // taps
-  static constexpr int NCH = (NT * 8 + 31) / 32;                // 32-column chunks of the (tap, thin channel) columns: 7 / 13
+  static constexpr int NCH = (NT * TCOL + 31) / 32;             // 32-column chunks of the (tap, thin channel) columns: 7 / 13 / 5
   static constexpr int NQ = (NCH + 1) / 2;                      // chunks per wave pair
   static constexpr int HH = STR * (W5_TH - 1) + 2 * TR + 1, HW = STR * (W5_TW - 1) + 2 * TR + 1;  // halo: 12 x 20 / 21 x 37
-  static constexpr int Y_BYTES = HH * HW * 16 + 64;             // halo image + a zero line for the column groups past the last tap
+  static constexpr int YP = 2 * TCOL;                           // bytes of a halo pixel
+  static constexpr int Y_BYTES = HH * HW * YP + 64;             // halo image + a zero line for the column groups past the last tap
   static constexpr int LDS = W5_A_BYTES + Y_BYTES;
   static constexpr int NYL = (HH * HW + NTHREADS - 1) / NTHREADS;  // halo pixels per thread
 };
@@ -53,13 +55,21 @@ __device__ __forceinline__ typename TT<T>::vec w5_frag(const w5_u32x2& lo, const
 }
 
 // PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient);
-// PY = prologue of the thin operand: 1 BN+ReLU (the raw-input channels of the head's first convolution sit behind norm0), 0 none
+// PY = prologue of the thin operand: 1 BN+ReLU (the raw-input channels of the head's first convolution sit behind norm0), 0 none,
+//      2 (round 5) the two FACTORS of that activation: relu(bn(x)) = gamma * (m * xhat) + beta * m with m = [bn(x) > 0] and xhat the
+//      normalised input.  The halo pixel holds [m * xhat (8 channels) | m (8 channels)], the kernel correlates both with the output
+//      gradient - S2[c][tap][n] = sum_p gY[p][c] (m xhat)[p + tap][n], S1 likewise with m - and writes them to `sbuf` instead of the
+//      packed gradient.  From S1, S2 follow BOTH the weight gradient dW = gamma S2 + beta S1 AND the BatchNorm-backward reductions of the
+//      raw-input channels, sum dz = sum_{c,tap} W[c][n][tap] S1[c][tap][n] and sum dz xhat likewise with S2 (wg5_rawfin_kernel) - the
+//      full-resolution data gradient towards the raw input (0.69 ms, one more pass over the 1.26 GB gradient at C2) existed only for
+//      those two sums per channel.
 template <typename T, int TR, int STR, int PA, int PY>
 __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
-  typedef W5Geo<TR, STR> G5;
-  constexpr int W5_HH = G5::HH, W5_HW = G5::HW, W5_NCH = G5::NCH, NYL = G5::NYL;
+  constexpr int TCOL = PY == 2 ? 16 : 8;
+  typedef W5Geo<TR, STR, TCOL> G5;
+  constexpr int W5_HH = G5::HH, W5_HW = G5::HW, W5_NCH = G5::NCH, NYL = G5::NYL, YP = G5::YP;
   constexpr int SLOT = 8;
   constexpr int NA = BM * (W5_CA / SLOT) / NTHREADS;  // 4 A slots per thread
   const WgradArgs& a = g.w;
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
   unsigned char* Ys = smem + W5_A_BYTES;
-  constexpr int ZERO = W5_HH * W5_HW * 16;  // offset of the zero line in the dY image
+  constexpr int ZERO = W5_HH * W5_HW * YP;  // offset of the zero line in the dY image
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t_beg = blockIdx.x * g.tiles_per_wg, t_end = min(g.ntiles, t_beg + g.tiles_per_wg);
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   SlotK<SLOT> kyk;  // the thin operand's eight channels: the same constants for every thread
   kyk.k0 = 0.f; kyk.k1 = 0.f; kyk.k2 = 0.f; kyk.k3 = 0.f;
   if (PY == 1) { kyk.k0 = load_fv<SLOT>(sy.scale); kyk.k1 = load_fv<SLOT>(sy.shift); }
+  if (PY == 2) { kyk.k0 = load_fv<SLOT>(sy.scale); kyk.k1 = load_fv<SLOT>(sy.shift); kyk.k2 = load_fv<SLOT>(a.t_mean); kyk.k3 = load_fv<SLOT>(a.t_invstd); }
   int alds[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -145,9 +156,23 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
     for (int i = 0; i < NYL; ++i) {
       const int hp = tid + NTHREADS * i;
       if (hp < W5_HH * W5_HW) {
-        V v = R.ry[i];
-        if constexpr (PY == 1) v = bn_relu_slot(R.ry[i], kyk);
-        *(V*)(Ys + hp * 16) = ((R.oky >> i) & 1) ? v : z;  // zero padding applies AFTER the prologue
+        if constexpr (PY == 2) {
+          float xf[SLOT], mx[SLOT], mm[SLOT];
+          vec_to_f32<T>(R.ry[i], xf);
+#pragma unroll
+          for (int e = 0; e < SLOT; ++e) {
+            const bool on = fmaf(xf[e], kyk.k0[e], kyk.k1[e]) > 0.f;    // the forward's own test (scale / shift of the same tables)
+            mm[e] = on ? 1.f : 0.f;
+            mx[e] = on ? (xf[e] - kyk.k2[e]) * kyk.k3[e] : 0.f;
+          }
+          const bool ok = (R.oky >> i) & 1;
+          *(V*)(Ys + hp * YP) = ok ? f32_to_vec<T>(mx) : z;
+          *(V*)(Ys + hp * YP + 16) = ok ? f32_to_vec<T>(mm) : z;
+        } else {
+          V v = R.ry[i];
+          if constexpr (PY == 1) v = bn_relu_slot(R.ry[i], kyk);
+          *(V*)(Ys + hp * 16) = ((R.oky >> i) & 1) ? v : z;  // zero padding applies AFTER the prologue
+        }
       }
     }
   };
@@ -170,13 +195,15 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
 #pragma unroll
   for (int m = 0; m < NQ; ++m) {
     const int q = q0 + 2 * m;
-    const int tap = 4 * q + 2 * (tg & 1) + (tp >> 1);
+    // TCOL = 8: tap 4 q + 2 (tg & 1) + (tp >> 1), channels 4 (tp & 1) ..; TCOL = 16: tap 2 q + (tg & 1), variant tp >> 1, channels 4 (tp & 1) ..
+    const int tap = TCOL == 8 ? 4 * q + 2 * (tg & 1) + (tp >> 1) : 2 * q + (tg & 1);
+    const int sub = TCOL == 8 ? (tp & 1) * 8 : (tp >> 1) * 16 + (tp & 1) * 8;
     const bool live = q < W5_NCH && tap < sy.ntaps;
     const int tw = sy.taps[live ? tap : 0];
     const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
-    boff[m] = live ? ((TR + dy) * W5_HW + STR * arow + TR + dx) * 16 + (tp & 1) * 8 : ZERO + (tp & 1) * 8;
-    bstep[m] = live ? STR * W5_HW * 16 : 0;  // one tile row further in the halo image
-    bsec[m] = live ? STR * 4 * 16 : 0;       // the fragment's second half: 4 pixels further
+    boff[m] = live ? ((TR + dy) * W5_HW + STR * arow + TR + dx) * YP + sub : ZERO + (tp & 1) * 8;
+    bstep[m] = live ? STR * W5_HW * YP : 0;  // one tile row further in the halo image
+    bsec[m] = live ? STR * 4 * YP : 0;       // the fragment's second half: 4 pixels further
   }
 
   auto contract = [&]() {
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * h;
-      atomic_add_f32(a.dpack + ((size_t)q * a.Npad + c) * 32 + r, acc[m][i]);
+      atomic_add_f32((PY == 2 ? a.sbuf : a.dpack) + ((size_t)q * a.Npad + c) * 32 + r, acc[m][i]);
     }
   }
 }
@@ -231,7 +258,7 @@ void wg5_set_enabled(bool on) { g_wg5 = on; }
 template <typename T, int TR, int STR, int PA, int PY = 0>
 static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
   auto kern = wg5_kernel<T, TR, STR, PA, PY>;
-  constexpr int lds = W5Geo<TR, STR>::LDS;
+  constexpr int lds = W5Geo<TR, STR, PY == 2 ? 16 : 8>::LDS;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), lds, st, g);
   return hipGetLastError();
 }
@@ -252,6 +279,8 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
       q.Ws != str * a.Wo || (q.scale != nullptr) != raw3 || q.q != nullptr)
     return hipErrorNotSupported;
   if (q.nchunks != (q.ntaps * 8 + 31) / 32) return hipErrorNotSupported;
+  const bool factors = a.sbuf != nullptr;   // PY = 2: the activation's two factors, results to sbuf
+  if (factors && !(raw3 && a.t_mean != nullptr && a.t_invstd != nullptr)) return hipErrorNotSupported;
   if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo) return hipErrorNotSupported;
   if ((stem || raw3) ? p.scale != nullptr : (p.scale == nullptr || p.q != nullptr)) return hipErrorNotSupported;
   if (a.N != W5_CA || a.Npad != W5_CA) return hipErrorNotSupported;
@@ -276,6 +305,10 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;
   nwg = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
   const bool f16t = dtype == DT_F16;
+  if (raw3 && factors) {
+    if (p.q) return f16t ? launch_wg5_t<f16, 1, 1, 2, 2>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 2, 2>(g, nwg, st);
+    return f16t ? launch_wg5_t<f16, 1, 1, 0, 2>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 0, 2>(g, nwg, st);
+  }
   if (raw3) {
     if (p.q) return f16t ? launch_wg5_t<f16, 1, 1, 2, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 2, 1>(g, nwg, st);
     return f16t ? launch_wg5_t<f16, 1, 1, 0, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 0, 1>(g, nwg, st);
@@ -283,6 +316,40 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
   if (!stem) return f16t ? launch_wg5_t<f16, 2, 1, 1>(g, nwg, st) : launch_wg5_t<bf16, 2, 1, 1>(g, nwg, st);
   if (p.q) return f16t ? launch_wg5_t<f16, 3, 2, 2>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 2>(g, nwg, st);
   return f16t ? launch_wg5_t<f16, 3, 2, 0>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 0>(g, nwg, st);
+}
+
+// From the factor correlations S (wg5_kernel, PY = 2; layout [chunk][64 output channels c][32 columns], column 32 chunk + k = 16 tap +
+// 8 variant + n, variant 0 = S2 (m xhat), 1 = S1 (m)) to
+//   * the packed weight gradient of the raw-input segment, dP[(8 tap + n) / 32][c][(8 tap + n) % 32] += gamma[n] S2 + beta[n] S1, and
+//   * the BatchNorm-backward reductions of the raw-input channels (fp64): red1[n] += sum_{c,tap} W[c][n][tap] S1, red2[n] likewise with S2
+//     (the forward convolution's own master weights: W[c][koff + n][tapw[tap]] of a [64][Kin][9] tensor).
+// One workgroup: 64 x 9 x 8 = 4608 (c, tap, n) triples, 18 per thread.
+__global__ __launch_bounds__(256) void wg5_rawfin_kernel(const RawFinArgs a) {
+  __shared__ double r1[8], r2[8];
+  const int tid = threadIdx.x;
+  if (tid < 8) { r1[tid] = 0.0; r2[tid] = 0.0; }
+  __syncthreads();
+  for (int i = tid; i < 64 * 9 * 8; i += 256) {
+    const int n = i & 7, tap = (i >> 3) % 9, c = i / 72;
+    const int j = 16 * tap + n;                                            // S2 column; S1: + 8
+    const float s2 = a.sbuf[((size_t)(j >> 5) * 64 + c) * 32 + (j & 31)];
+    const float s1 = a.sbuf[((size_t)((j + 8) >> 5) * 64 + c) * 32 + ((j + 8) & 31)];
+    const int jp = 8 * tap + n;
+    a.dpack[((size_t)(jp >> 5) * a.Npad + c) * 32 + (jp & 31)] += a.gamma[n] * s2 + a.beta[n] * s1;
+    if (n < a.nreal) {
+      const double w = (double)a.w[((size_t)c * a.Kin + a.koff + n) * 9 + a.tapw[tap]];
+      atomicAdd(&r1[n], w * (double)s1);
+      atomicAdd(&r2[n], w * (double)s2);
+    }
+  }
+  __syncthreads();
+  if (tid < a.nreal) { a.red1[tid] += r1[tid]; a.red2[tid] += r2[tid]; }   // (replica 0; this launch is the only writer of these channels)
+}
+
+hipError_t launch_wg5_rawfin(const RawFinArgs& a, hipStream_t st) {
+  if (g_ctl.dry) return hipSuccess;
+  hipLaunchKernelGGL(wg5_rawfin_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 bool wg5_handles(const WgradArgs& a, int dtype) {

@@ -427,6 +427,50 @@ def test_head_weight_gradient_phases_in_one_launch(dtype, tol, monkeypatch):
         assert _rel(grads[0][k2], grads[1][k2]) < 2e-3, k2
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-3), ("bf16", 1.5e-2)])
+def test_raw_input_batchnorm_sums_from_the_weight_gradient(dtype, tol, monkeypatch):
+    """Round 5: the head's first convolution reads the raw input behind norm0 (reference M:123-127), so backward needs sum dz and
+    sum dz * xhat over the full-resolution map for those (<= 8) channels - for nothing but their gamma / beta gradients.  Round 4 ran
+    the 3x3 data gradient towards the raw input for that (one more pass over the 64-channel full-resolution gradient).  Now the
+    weight-gradient launch of that segment (wg5.hip) correlates the gradient with the two factors of the activation,
+    relu(bn(x)) = gamma (m xhat) + beta m, and a one-workgroup launch derives the packed weight gradient AND both sums from the result
+    (sum dz = sum W S1, sum dz xhat = sum W S2).  Against the data-gradient path (DMM_NO_RAW_STATS=1): norm0's gamma / beta gradients
+    on the raw-input channels, refine0's weight gradient on its raw-input segment, and every other gradient; the launch list holds
+    the finish launch and no data gradient towards the raw input."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=23))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=8))
+    grads, labs = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_RAW_STATS", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_RAW_STATS", raising=False)
+        model.close()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labs[off] = plan_labels(model._last[0], lists=(1,))
+        grads[off] = {k: p.grad.detach().double().cpu().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_RAW_STATS", raising=False)
+    model.close()
+    assert sum(lab.startswith("wg5.rawfin") for lab in labs[0]) == 1 and not any(lab.startswith("wg5.rawfin") for lab in labs[1])
+    raw_dgrad = [lab for lab in labs[1] if ".bnbwd.n32/h.refine0" in lab]
+    assert len(raw_dgrad) == 1 and not any(".bnbwd.n32/h.refine0" in lab for lab in labs[0]), (raw_dgrad, [l for l in labs[0] if "refine0" in l])
+    nfl = 128
+    for k in ("dec_out_to_heat_maps.norm0.weight", "dec_out_to_heat_maps.norm0.bias"):
+        a, b = grads[0][k][nfl:], grads[1][k][nfl:]
+        assert float(b.abs().max()) > 0 and a.numel() == 6
+        assert float((a - b).abs().max() / b.abs().max()) < tol, (k, a, b)
+    a, b = grads[0]["dec_out_to_heat_maps.refine0.weight"][:, nfl:], grads[1]["dec_out_to_heat_maps.refine0.weight"][:, nfl:]
+    assert float((a - b).norm() / b.norm()) < tol, float((a - b).norm() / b.norm())
+    for k in grads[0]:
+        assert _rel(grads[0][k], grads[1][k]) < max(tol, 2e-3), k
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 def test_decoder_weight_gradient_phases_in_one_launch(dtype, monkeypatch):
     """Round 5: the four output-parity phases of a decoder ConvTranspose's weight gradient (1, 2, 2 and 4 taps) run as ONE launch of the
