@@ -766,7 +766,7 @@ static void fill_one_seg(Seg& s, const dmm_conv_desc* d, const OneConv& g, const
 int dmm_last_impl(void) { return g_last_impl; }
 unsigned dmm_impl_mask(int reset) { const unsigned m = g_impl_mask; if (reset) g_impl_mask = 0; return m; }
 const char* dmm_impl_name(int impl) {
-  static const char* const names[IMPL_COUNT] = {"auto", "generic", "thin", "conv3", "cvp", "halo", "wg3", "wg5", "wgp", "pig", "bw1", "hf", "cf", "wgpw"};
+  static const char* const names[IMPL_COUNT] = {"auto", "generic", "thin", "conv3", "cvp", "halo", "wg3", "wg5", "wgp", "pig", "bw1", "hf", "cf", "wgpw", "cvw"};
   return impl >= 0 && impl < IMPL_COUNT ? names[impl] : "?";
 }
 

@@ -176,7 +176,7 @@ constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at mos
 // wgrad_pick walk the dispatch without launching and honour the dmm_set_option switches of that moment) and the executor
 // dispatches from the recorded value, so a plan's labels, its profile classes and the kernels it runs cannot drift apart when an
 // option is toggled afterwards.  IMPL_AUTO (the single-kernel test entry points): decide at the call.
-enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG, IMPL_BW1, IMPL_HF, IMPL_CF, IMPL_WGPW /* wgp in its wave-specialised form: noted beside IMPL_WGP */, IMPL_COUNT };
+enum Impl { IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_THIN, IMPL_CONV3, IMPL_CVP, IMPL_HALO, IMPL_WG3, IMPL_WG5, IMPL_WGP, IMPL_PIG, IMPL_BW1, IMPL_HF, IMPL_CF, IMPL_WGPW /* wgp in its wave-specialised form: noted beside IMPL_WGP */, IMPL_CVW /* likewise cvp forward (cvw.hip) */, IMPL_COUNT };
 struct LaunchCtl {
   bool dry = false;      // walk the eligibility tests, launch nothing
   int impl = IMPL_AUTO;  // the one family allowed to take the launch (IMPL_AUTO: every enabled family, in dispatch order)

@@ -526,6 +526,9 @@ static hipError_t launch_cvp_t(const CvpArgs& g, int nwg, hipStream_t st) {
 }
 
 static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st);
+// the wave-specialised forward (cvw.hip, round 5)
+hipError_t launch_cvw(const ConvArgs& a, int dtype, const int* ph_dymin, const int* ph_dxmin, hipStream_t st);
+static const bool g_cvw = !lab_flag("DMM_NO_CVW");
 
 // Takes a forward launch (EPI_STORE) with one plain segment of a multiple of 128 BN+ReLU-normalised input channels whose 1, 2 or
 // 4 taps lie in a 2x2 box, a multiple of 128 padded output columns, 16-bit storage.  Returns hipErrorNotSupported otherwise.
@@ -572,6 +575,11 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
       g.ph_dymin[ph] = (signed char)dy0; g.ph_dxmin[ph] = (signed char)dx0;
     }
     if (g_ctl.dry) return hipSuccess;
+    if (g_cvw) {
+      const int dy4[4] = {g.ph_dymin[0], g.ph_dymin[1], g.ph_dymin[2], g.ph_dymin[3]}, dx4[4] = {g.ph_dxmin[0], g.ph_dxmin[1], g.ph_dxmin[2], g.ph_dxmin[3]};
+      const hipError_t e = launch_cvw(a, dtype, dy4, dx4, st);
+      if (e != hipErrorNotSupported) return e;
+    }
     g.c = a;
     g.dymin = g.dxmin = 0;
     g.tiles_y = (a.Ho + CP_TH - 1) / CP_TH;
@@ -595,6 +603,11 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   }
   if (dymax - dymin > 1 || dxmax - dxmin > 1) return hipErrorNotSupported;
   if (g_ctl.dry) return hipSuccess;
+  if (g_cvw && a.ostride == 2) {
+    const int dy4[4] = {dymin, 0, 0, 0}, dx4[4] = {dxmin, 0, 0, 0};
+    const hipError_t e = launch_cvw(a, dtype, dy4, dx4, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   CvpArgs g;
   g.c = a;
   g.dymin = dymin; g.dxmin = dxmin;

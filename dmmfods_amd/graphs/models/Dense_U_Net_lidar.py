@@ -12,6 +12,7 @@ import ctypes as C
 import math
 import os
 import re
+import sys
 from collections import OrderedDict
 
 import torch
@@ -136,8 +137,7 @@ class _Plan:
         # that is still open when the garbage collector finds it is closed here and the fact is reported, never swallowed.  While the
         # interpreter is finalising nothing is done: module globals (ctypes, torch, this module's _lib) may already be gone, and
         # the process's exit releases the plan - NOT because the HIP runtime would be unloaded (it is not: round 4's guess).
-        import sys
-        if sys is None or sys.is_finalizing() or not getattr(self, "handle", None):
+        if sys is None or sys.is_finalizing() or not getattr(self, "handle", None):   # (module-level import: nothing can be imported at shutdown)
             return
         try:
             self.close()

@@ -371,6 +371,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
     rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=3))
     grads, labels = {}, {}
     monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")     # (held-back phase launches are not merged into one: compare like with like)
+    monkeypatch.setenv("DMM_NO_RAW_STATS", "1")     # (nor does a held-back raw-segment weight gradient feed the norm's sums: round 5)
     for off in (0, 1):
         if off:
             monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
@@ -384,6 +385,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
     monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
+    monkeypatch.delenv("DMM_NO_RAW_STATS", raising=False)
     model.close()
     assert sorted(labels[0]) == sorted(labels[1])
     first_head_w = {o: next(i for i, lab in enumerate(labels[o]) if lab.startswith(("wgp.", "wg5.")) and "/h." in lab) for o in (0, 1)}

@@ -11,7 +11,7 @@ CLANG=/opt/rocm/lib/llvm/bin/clang++
 FLAGS="-x hip --offload-host-only --offload-arch=gfx950 -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -w $DRIVE_EXTRA_FLAGS"
 pids=()
 cc() { $CLANG $FLAGS "${@:3}" -c "$1" -o "$OUT/$2" & pids+=($!); if [ ${#pids[@]} -ge 8 ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi; }
-for f in bw1 cf conv3 cvp halo hf pig pointwise thin wg3 wg5 wgp wgpw; do cc "$SRC/$f.hip" "$f.o"; done
+for f in bw1 cf conv3 cvp cvw halo hf pig pointwise thin wg3 wg5 wgp wgpw; do cc "$SRC/$f.hip" "$f.o"; done
 cc "$SRC/halo.hip" halo32.o -DHALO_F32_PART
 for p in 0 1 2; do n=(f32 f16 bf16); cc "$SRC/igemm.hip" "igemm_${n[$p]}.o" -DIGEMM_PART=$p; cc "$SRC/wgrad.hip" "wgrad_${n[$p]}.o" -DWGRAD_PART=$p; done
 cc "$SRC/plan.cpp" plan.o
