@@ -55,15 +55,7 @@ def test_parity_phase_weight_gradients_on_lds_tiles(lab, dtype):
              ("convT 128->128 1 tile", 1, 3, 5, 128, 128, 3, 3, 2, 1, 1, 0, 1),
              ("up2 3x3 128->64", 2, 10, 18, 128, 64, 3, 3, 1, 1, 0, 1, 1)]
     for c in cases:
-        _lib.impls_since_reset()
         assert lab.conv_case(c[0], dtype, 1, *c[1:])
-        ran = _lib.impls_since_reset()
-        # round 5: the ConvTranspose forward runs in its wave-specialised form (cvw.hip: 4 matrix + 4 loader waves, persistent), the
-        # weight gradients of the multi-tap phases in theirs (wgpw.hip) - both noted beside their families
-        if c[0].startswith("convT") and c[4] % 128 == 0 and c[5] % 128 == 0:
-            assert "cvp" in ran and "cvw" in ran, (c[0], sorted(ran))
-        if c[0].startswith("convT") and c[5] % 64 == 0:
-            assert "wgp" in ran and "wgpw" in ran, (c[0], sorted(ran))
     try:
         _lib.check(L.dmm_set_option(b"wgp", 0))
         _lib.check(L.dmm_set_option(b"cvp", 0))

@@ -91,8 +91,11 @@ PRODUCTION = [  # name, B, H, W, Cin, Cout, R, stride, pad, bn, transposed, fami
     ("dense 1x1 224->128 @320x480", 4, 320, 480, 224, 128, 1, 1, 0, 1, 0, "pig"),
     ("dense 1x1 992->128 @80x120", 4, 80, 120, 992, 128, 1, 1, 0, 1, 0, "pig"),      # K-deep: 16 stages behind counted waits (pig.hip)
     ("dense 1x1 1024->128 @40x60", 4, 40, 60, 1024, 128, 1, 1, 0, 1, 0, "pig"),     # ... on 75 tiles
-    ("convT 128->128 @320x480", 4, 320, 480, 128, 128, 3, 2, 1, 1, 1, "cvp"),
-    ("convT 512->512 @80x120", 4, 80, 120, 512, 512, 3, 2, 1, 1, 1, "cvp"),
+    ("convT 128->128 @320x480", 4, 320, 480, 128, 128, 3, 2, 1, 1, 1, "cvw"),       # round 5: the wave-specialised persistent form (cvw.hip: stages
+    ("convT 256->256 @160x240", 4, 160, 240, 256, 256, 3, 2, 1, 1, 1, "cvw"),       # of one or two channel groups), noted beside its family cvp
+    ("convT 256->256 @44x52 ragged", 2, 44, 52, 256, 256, 3, 2, 1, 1, 1, "cvw"),    # ragged tiles in both directions, fewer items than workgroups x phases
+    ("convT 512->512 @80x120", 4, 80, 120, 512, 512, 3, 2, 1, 1, 1, "cvp"),         # deeper stages stay on cvp.hip (measured: DESIGN 4)
+    ("convT 1024->1024 @40x60", 4, 40, 60, 1024, 1024, 3, 2, 1, 1, 1, "cvp"),
 ]
 
 
