@@ -102,6 +102,7 @@ def lib():
     L.dmm_conv_wgrad_ex.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.dmm_conv_dgrad_ex.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.dmm_conv1x1_backward_fused.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.dmm_conv5_wgrad_stats.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -113,7 +114,7 @@ EXPORTS = [
     "dmm_plan_loss_metrics", "dmm_plan_num_graph_replays", "dmm_plan_set_loss", "dmm_loss_forward", "dmm_plan_num_grad_buckets", "dmm_plan_grad_bucket",
     "dmm_plan_grad_bucket_wait", "dmm_plan_profile_begin", "dmm_plan_profile_filter", "dmm_plan_profile_num_ops", "dmm_plan_profile_op",
     "dmm_plan_profile_collect", "dmm_adam_step", "dmm_conv_scratch_bytes", "dmm_conv_forward", "dmm_conv_wgrad",
-    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused", "dmm_last_impl", "dmm_impl_name", "dmm_impl_mask",
+    "dmm_conv_dgrad", "dmm_conv_wgrad_ex", "dmm_conv_dgrad_ex", "dmm_conv1x1_backward_fused", "dmm_conv5_wgrad_stats", "dmm_last_impl", "dmm_impl_name", "dmm_impl_mask",
 ]
 
 

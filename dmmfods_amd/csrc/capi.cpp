@@ -332,7 +332,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       // the side stream is forked in THIS call: a range that starts mid-chain, or a join inside the chain, makes the next launch
       // of the chain fork again like any leaf.
       lst = side_st;
-    } else if (overlap && (o.kind == OP_WGRAD || o.leaf)) {
+    } else if (overlap && !o.chain && (o.kind == OP_WGRAD || o.leaf)) {
       if (nfork >= p->fork_events.size()) {
         hipEvent_t fe = pool_event(dp, false);
         if (fe == nullptr) { join(); return fail(DMM_ERR_HIP, "hipEventCreate failed"); }
@@ -356,6 +356,7 @@ static int run_ops(dmm_plan* p, std::vector<Op>& ops, hipStream_t st, int prof_w
       case OP_BW1: e = launch_bw1(o.b1, dt, lst); break;
       case OP_BW1RED: e = launch_bw1_reduce(o.b1, lst); break;
       case OP_RAWFIN: e = launch_wg5_rawfin(o.rf, lst); break;
+      case OP_FIN64: e = launch_wg5_fin64(o.f64, lst); break;
       case OP_JOIN: if (o.epi == 1) join_pack(); else join_side(); break;  // the main stream waits for what the side (epi 1: pack) stream has been given so far
       case OP_BNFIN: e = launch_bn_finalize(o.bf, lst); break;
       case OP_BNBWD: e = launch_bn_bwd_finalize(o.bb, lst); break;
@@ -750,7 +751,7 @@ size_t dmm_conv_scratch_bytes(const dmm_conv_desc* d) {
   // dgrad pack: [chunks][rup(Cin,32)][BK] with K' = R*S*rup(Cout,8)
   const size_t dg = (size_t)((d->R * d->S * rup(d->Cout, 8) + g.BK - 1) / g.BK + 16) * rup(d->Cin, 128) * g.BK * g.esz;
   // + the fp32 dgrad-shaped packed gradient of the transposed-form weight gradient, zero tables, descriptors
-  return fwd + dg + 2 * dg + (size_t)rup(d->Cout, 8) * 8 + 8192;
+  return fwd + dg + 2 * dg + (size_t)rup(d->Cout, 8) * 8 + 8192 + (size_t)W5_SBUF64_FLOATS * sizeof(float);
 }
 
 static void fill_one_seg(Seg& s, const dmm_conv_desc* d, const OneConv& g, const void* x, const float* scale, const float* shift,
@@ -899,6 +900,59 @@ int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, con
   }
   HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
   HIPCHK(launch_unpack(dd, dp, (int)packs.size(), total_rows, d->dtype, 1.0f, st));
+  return DMM_OK;
+}
+
+int dmm_conv5_wgrad_stats(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
+                          float* dw, double* red, void* scratch, void* stream) {
+  OneConv g;
+  if (!d || !geometry(d, g)) return fail(DMM_ERR_INVALID, "unsupported conv descriptor");
+  if (d->transposed || d->mode != 0 || d->stride != 1 || d->R != 5 || d->S != 5 || d->pad != 2 || !d->bn_relu || d->Cin != 64 || d->Cout > 4 ||
+      d->dtype == DMM_F32 || !d->use_mfma)
+    return fail(DMM_ERR_INVALID, "serves the 5x5 convolution of 64 channels onto <= 4 behind BN+ReLU in 16-bit storage");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wn = (size_t)d->Cin * d->Cout * 25;
+  const std::vector<Tap> taps = taps_conv_dgrad(5, 5, 2);
+  Scratch S{(uint8_t*)scratch};
+  PackDesc* dd = (PackDesc*)S.take(sizeof(PackDesc));
+  int* dp = (int*)S.take(sizeof(int));
+  PackDesc pd = dgrad_pack_desc(d, g, taps, dw, 64);
+  const size_t elems = (size_t)pd.seg[0].nchunks * pd.Npad * g.BK;
+  pd.dpack = (float*)S.take(elems * sizeof(float));
+  pd.gw = dw;
+  float* sbuf = (float*)S.take((size_t)W5_SBUF64_FLOATS * sizeof(float));
+  if (S.off > dmm_conv_scratch_bytes(d)) return fail(DMM_ERR_INVALID, "scratch too small");
+  HIPCHK(hipMemsetAsync(scratch, 0, S.off, st));
+  HIPCHK(hipMemsetAsync(red, 0, 2 * (size_t)d->Cin * sizeof(double), st));
+  int zero = 0;
+  HIPCHK(upload(dd, &pd, sizeof(pd), st));
+  HIPCHK(upload(dp, &zero, sizeof(int), st));
+  HIPCHK(hipStreamSynchronize(st));
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nseg = 1;
+  Seg& sq = a.seg[0];  // Q: the output gradient under the flipped taps
+  sq.src = dy; sq.ld = d->Cout; sq.Hs = g.Hout; sq.Ws = g.Wout; sq.C = rup(d->Cout, 8); sq.Cpad = sq.C; sq.mode = G_PLAIN; sq.istride = 1;
+  fill_seg_taps(sq, taps, g.BK);
+  a.B = d->B; a.Ho = g.Ho; a.Wo = g.Wo; a.M = d->B * g.Ho * g.Wo;
+  fill_one_seg(a.dy, d, g, x, scale, shift, taps_conv(1, 1, 0));  // P: the input, entered as the two factors of its activation
+  a.dy.istride = 1;
+  a.N = g.Cst; a.Npad = pd.Npad;
+  a.dpack = (float*)pd.dpack;
+  a.sbuf = sbuf;
+  a.t_mean = shift + d->Cin; a.t_invstd = shift + 2 * d->Cin;
+  HIPCHK(launch_wgrad(a, d->dtype, true, st));
+  if (g_last_impl != IMPL_WG5) return fail(DMM_ERR_STATE, "the factor form is wg5.hip's");
+  Fin64Args f;
+  memset(&f, 0, sizeof(f));
+  f.sbuf = sbuf; f.dpack = a.dpack; f.Npad = a.Npad;
+  f.w = w; f.Kin = d->Cin; f.nreal = d->Cout; f.dtype = d->dtype;
+  for (int t = 0; t < 25; ++t) f.tapw[t] = (unsigned char)(pd.seg[0].tapw[t] & 0xff);
+  f.scale = scale; f.shift = shift; f.mean = shift + d->Cin; f.invstd = shift + 2 * d->Cin;
+  f.red1 = red; f.red2 = red + d->Cin;
+  HIPCHK(launch_wg5_fin64(f, st));
+  HIPCHK(hipMemsetAsync(dw, 0, wn * sizeof(float), st));
+  HIPCHK(launch_unpack(dd, dp, 1, pd.seg[0].nchunks * pd.Npad, d->dtype, 1.0f, st));
   return DMM_OK;
 }
 

@@ -148,7 +148,8 @@ struct WgradArgs {
   short ph_ytap[4];       // parity tap of dy per phase
   float* ph_dpack[4];
   // wg5.hip, PY = 2 (round 5): the thin operand enters as the two factors of its activation - batch mean / inverse std of its
-  // BatchNorm (scale / shift: seg[0]) - and the factor correlations go to sbuf [5][64][32] instead of dpack (nullable: off)
+  // BatchNorm (scale / shift: seg[0]) - and the factor correlations go to sbuf [5][64][32] instead of dpack (nullable: off).
+  // PA = 3 (25 taps): the same for the 64-channel operand `dy` (t_mean / t_invstd: 64 channels; sbuf [2][4][64][32]; the thin operand's real channels number <= 4)
   const float* t_mean;
   const float* t_invstd;
   float* sbuf;
@@ -169,6 +170,24 @@ struct RawFinArgs {
   double* red2;
 };
 constexpr int W5_SBUF_FLOATS = 5 * 64 * 32;
+// wg5_fin64_kernel (wg5.hip): from the factor correlations of the 64-channel operand (wg5_kernel, PA = 3) to the packed weight gradient
+// of the head's 5x5 convolution and the BatchNorm-backward reductions of the norm in front of it
+struct Fin64Args {
+  const float* sbuf;     // (doubles) [2][4][64][32]: variant 0 = S2 (m x), 1 = S1 (m); column 32 chunk + k = 4 tap + n
+  float* dpack;          // packed gradient [7][Npad][32]
+  int Npad;
+  const float* w;        // master weights [nreal][Kin][25] (the forward convolution's own)
+  int Kin, nreal;        // input channels of the convolution (64), its real output channels (classes, <= 4)
+  int dtype;             // storage type of the packed weights (DT_F16 / DT_BF16)
+  unsigned char tapw[28];  // master tap of packed tap t
+  const float* scale;    // norm1's forward constants, 64 channels: relu(bn(x)) = scale (m x) + shift m
+  const float* shift;
+  const float* mean;     // its batch statistics: sum dz xhat = (sum dz x - mean sum dz) invstd
+  const float* invstd;
+  double* red1;          // BatchNorm-backward reductions of the 64 channels, replica 0
+  double* red2;
+};
+constexpr int W5_SBUF64_FLOATS = 2 * 2 * 4 * 64 * 32;   // [2][4][64][32] doubles
 constexpr int W3_SLOT_FLOATS = 9 * 128 * 32;  // one workgroup's partial result of the dense 3x3 weight gradient (147 KB)
 constexpr int W3_MAX_SLOTS = 256;             // = workgroups of a launch at most (device-independent: plans are sized without a GPU)
 

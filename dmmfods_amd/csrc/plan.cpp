@@ -751,12 +751,23 @@ struct Builder {
     bool wt_deferred = false;
     Op wt_op;
     bool have_second = false;
+    bool r1_stats = false;    // (round 5) norm1's sums come from the 5x5 weight gradient: the reductions-only pass is not emitted
     bool raw_stats = false;   // (round 5) the raw-input channels' BatchNorm sums come from the weight gradient: no data gradient towards them
     Op second_pass;
     int second_buf = -1;
     if (c.wgrad_transposed && dtype != DT_F32 && c.R == 3 && c.S == 3 && Nst == 32 && c.nseg == 1 && c.seg[0].C == 128 &&
         c.seg[0].dgrad == DG_FLIP && !P.sw.no_eff_compact)
       eff_compact = wptr<uint8_t>((size_t)c.B * c.Ho * c.Wo * 32 * esz);
+    // Round 5 (second half): the head's 5x5 convolution onto the classes.  Its two-pass data gradient (below) ran a reductions-only
+    // FIRST pass over the 64-channel full-resolution activation for norm1's two sums; its weight gradient (wg5.hip) reads the same
+    // activation and the same logits gradient.  With the activation entered as its two factors (wg5.hip, PA = 3) the weight-gradient
+    // launch yields dW AND both sums (wg5_fin64_kernel): the first pass is not emitted, and the weight gradient - now the producer of
+    // what the chain needs next - runs on the main stream (Op::chain).  The buffer is reserved by shape alone.
+    float* r1_sbuf = nullptr;
+    int r1_idx = -1;
+    if (c.wgrad_transposed && dtype != DT_F32 && c.R == 5 && c.S == 5 && Nst == 8 && c.nseg == 1 && c.seg[0].C == 64 &&
+        c.seg[0].dgrad == DG_FLIP && c.N <= 4 && !P.sw.no_r1_stats && !P.sw.no_two_pass)
+      r1_sbuf = zbptr<float>(W5_SBUF64_FLOATS);
     if (c.wgrad_transposed) {
       Op& o = push(OP_WGRAD);
       WgradArgs& a = o.w;
@@ -784,6 +795,8 @@ struct Builder {
         ops->pop_back();
         wt_deferred = true;
       }
+      // the head's 5x5 convolution: a candidate for norm1's sums from the factor correlations (decided with the data gradient below)
+      if (r1_sbuf != nullptr && o.impl == IMPL_WG5 && !leaf_scope && !defer_scope && c.seg[0].bn >= 0) r1_idx = (int)ops->size() - 1;
     } else {
     // The head's first convolution (two segments, four output-parity phases): the phase split exists for the upsampled decoder
     // segment; the 8-channel raw-input segment is a plain 3x3 convolution over the full-resolution grid, whose weight gradient is ONE
@@ -904,7 +917,8 @@ struct Builder {
       ops->pop_back();
       pending_w = true;
     }
-    if (!pending_w && !wt_deferred) conv_grad_done(c);
+    const bool r1_wait = r1_idx >= 0;   // (the finish launch may still add into this convolution's packed gradient)
+    if (!pending_w && !wt_deferred && !r1_wait) conv_grad_done(c);
     // ---- data gradients with fused BN+ReLU backward ----
     for (int s = 0; s < c.nseg; ++s) {
       SegRec& sr = c.seg[s];
@@ -980,6 +994,29 @@ struct Builder {
             a.out = nullptr;
             o.bytes = out_bytes(c) + srcb + w_bytes(c);          // reads dy and x, writes nothing
             second_pass.bytes = out_bytes(c) + srcb * 2.0 + w_bytes(c);
+            if (r1_idx >= 0) {   // norm1's sums from the weight gradient's factor correlations: the first pass becomes the finish launch
+              WgradArgs f = (*ops)[r1_idx].w;
+              f.sbuf = r1_sbuf;
+              f.t_mean = bn.mean + sr.bn_c0; f.t_invstd = bn.invstd + sr.bn_c0;   // (mark of the factor form; the kernel needs scale / shift only)
+              if (wgrad_pick(f, dtype, d.use_mfma != 0) == IMPL_WG5) {
+                Op& wo = (*ops)[r1_idx];
+                wo.w = f;
+                wo.chain = 1;
+                const PackDesc& wpd = P.packs[c.dpack[0]];
+                Fin64Args r;
+                memset(&r, 0, sizeof(r));
+                r.sbuf = r1_sbuf; r.dpack = f.dpack; r.Npad = f.Npad;
+                r.w = Pp + T(c.wname).off; r.Kin = c.Kin; r.nreal = c.N; r.dtype = dtype;
+                for (int t = 0; t < 25; ++t) r.tapw[t] = (unsigned char)(wpd.seg[0].tapw[t] & 0xff);
+                r.scale = bn.scale + sr.bn_c0; r.shift = bn.shift + sr.bn_c0;
+                r.mean = bn.mean + sr.bn_c0; r.invstd = bn.invstd + sr.bn_c0;
+                r.red1 = bn.red1 + sr.bn_c0; r.red2 = bn.red2 + sr.bn_c0;
+                o.kind = OP_FIN64; o.epi = 0; o.impl = IMPL_AUTO; o.chain = 1;
+                o.f64 = r;     // (overwrites the first pass's arguments: `a` is dead from here on)
+                tag(o, "wg5.fin64", short_name(c.wname), 0, W5_SBUF64_FLOATS * 4.0);
+                r1_stats = true;
+              }
+            }
           }
         }
       }
@@ -1026,6 +1063,7 @@ struct Builder {
     }
     if (pending_w) { ops->push_back(saved_w); conv_grad_done(c); pending_w = false; }  // (no data gradient was emitted)
     if (wt_deferred) { ops->push_back(wt_op); conv_grad_done(c); }
+    if (r1_wait) conv_grad_done(c);
     int done = -1;
     if (have_second) bufs[second_buf].materialized = true;   // (no apply_corr behind the finalize: the second pass stores the final gradient)
     for (int s = 0; s < c.nseg; ++s) {
@@ -1693,6 +1731,7 @@ PlanSwitches PlanSwitches::from_environment() {
   s.no_s2_interleave = on("DMM_NO_S2_INTERLEAVE");
   s.defer_wgrad = on("DMM_DEFER_WGRAD");
   s.no_raw_stats = on("DMM_NO_RAW_STATS");
+  s.no_r1_stats = on("DMM_NO_R1_STATS");
   const char* pc = getenv("DMM_PACK_CUT");
   s.pack_cut = pc ? std::max(1, atoi(pc)) : 0;
   return s;

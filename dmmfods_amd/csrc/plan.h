@@ -37,7 +37,7 @@ void fill_seg_taps(Seg& s, const std::vector<Tap>& taps, int BK);
 void fill_pack_seg(PackSeg& p, const std::vector<Tap>& taps, int Creal, int Cpad, int koff, int BK);
 
 enum OpKind { OP_MEMSET = 0, OP_CONVERT, OP_IGEMM, OP_WGRAD, OP_BNFIN, OP_BNBWD, OP_POOL, OP_POOLBWD, OP_BCE, OP_PACK, OP_UNPACK,
-              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN, OP_BW1RED, OP_RAWFIN };
+              OP_COPY, OP_APPLYCORR, OP_BW1, OP_JOIN, OP_BW1RED, OP_RAWFIN, OP_FIN64 };
 
 struct MemsetArgs { void* p; size_t bytes; };
 struct CopyArgs { void* dst; const void* src; size_t bytes; };
@@ -51,6 +51,8 @@ struct Op {
   int epi;
   int leaf;        // nothing on the data-gradient chain reads what this launch produces (may run beside it): 1 side stream, forked from
                    // the main stream; 3 side stream, continuing the chain of the launch in front of it there (no fork); 2 pack stream
+  int chain;       // 1: a weight-gradient-side launch the data-gradient chain WAITS for (its results feed the next launch of the chain):
+                   // it runs on the main stream although its kind says side stream
   int signal;      // gradient bucket event to record behind this launch on the stream it ran on (-1: none)
   int impl;        // kernel family (enum Impl) chosen for this launch when the plan was built
   double flops;    // algorithmic 2*MACs of this launch (reference formulation)
@@ -71,8 +73,9 @@ struct Op {
     ApplyCorrArgs ac;
     Bw1Args b1;
     RawFinArgs rf;
+    Fin64Args f64;
   };
-  Op() : kind(0), epi(0), leaf(0), signal(-1), impl(IMPL_AUTO), flops(0), bytes(0) { label[0] = 0; }
+  Op() : kind(0), epi(0), leaf(0), chain(0), signal(-1), impl(IMPL_AUTO), flops(0), bytes(0) { label[0] = 0; }
 };
 
 }  // namespace dmm
@@ -99,13 +102,15 @@ struct GradBucket {
 //   DMM_NO_S2_INTERLEAVE=1  mid fusion: the second encoder's launch records behind the first's instead of alternating
 //   DMM_PACK_CUT=<n>        the forward record in front of which the late layers' weight pack is joined (1 = behind the stem)
 //   DMM_DEFER_WGRAD=1       the head's / decoder's multi-tap weight gradients held back until backward reaches the encoder
+//   DMM_NO_R1_STATS=1       the BatchNorm-backward sums of the head's norm1 from the reductions-only first pass of the 5x5 data gradient
+//                           instead of from the 5x5 weight gradient's factor correlations (wg5.hip, PA = 3)
 //   DMM_NO_RAW_STATS=1      the BatchNorm-backward sums of the head's raw-input channels from a data-gradient pass of their own
 //                           (round 4) instead of from the weight gradient's factor correlations (wg5.hip, PY = 2)
 // Process-wide (capi.cpp, read when the library is loaded; also dmm_set_option): DMM_NO_OVERLAP, DMM_GRAPH, DMM_GRAD_BUCKET_MB;
 // diagnostics: DMM_TRACE_DESTROY.  Everything else that used to be an environment switch is a compile-time lab knob (common.h).
 struct PlanSwitches {
   bool no_pack_tiles = false, no_hf = false, no_c3_merge = false, no_cvp_merge = false, no_wgp_merge = false, no_two_pass = false,
-       no_eff_compact = false, no_s2_interleave = false, defer_wgrad = false, no_raw_stats = false;
+       no_eff_compact = false, no_s2_interleave = false, defer_wgrad = false, no_raw_stats = false, no_r1_stats = false;
   int pack_cut = 0;  // 0: by weight count
   static PlanSwitches from_environment();
 };

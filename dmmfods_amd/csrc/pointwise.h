@@ -185,6 +185,7 @@ bool wg3_handles(const WgradArgs& a, int dtype);
 bool wgp_handles(const WgradArgs& a, int dtype);
 bool wg5_handles(const WgradArgs& a, int dtype);
 hipError_t launch_wg5_rawfin(const RawFinArgs& a, hipStream_t st);
+hipError_t launch_wg5_fin64(const Fin64Args& a, hipStream_t st);
 hipError_t launch_convert_input(const ConvertArgs& a, int dtype, hipStream_t st);
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t st);

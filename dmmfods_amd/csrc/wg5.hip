@@ -23,7 +23,9 @@ constexpr int W5_CA = 64;
 constexpr int W5_A_BYTES = BM * W5_CA * 2;                    // 16 KB, 128-byte rows, 64-byte granule XOR-ed with (row >> 1) & 1
 // TR = tap radius, STR = source stride of the thin operand: (5x5, stride 1) = the head's last convolution; (7x7, stride 2) = the
 // stem convolution conv0 (reference M:47-52 / torchvision features.conv0), whose thin operand is the raw input.
-// TCOL = columns per tap: 8 (the thin operand's eight channels) or 16 (PY == 2: two variants of each channel, see below)
+// TCOL = columns per tap: 8 (the thin operand's eight channels), 16 (PY == 2: two variants of each channel, see below) or 4 (PA == 3: the
+//        first four channels of the thin operand only - its real channels, the classes, must number <= 4 - so that the 25 taps are
+//        four 32-column chunks instead of seven; the column order is private to wg5_kernel<PA = 3> and wg5_fin64_kernel)
 template <int TR, int STR, int TCOL = 8>
 struct W5Geo {
   static constexpr int NT = (2 * TR + 1) * (2 * TR + 1);        // taps
@@ -33,6 +35,7 @@ struct W5Geo {
   static constexpr int YP = 2 * TCOL;                           // bytes of a halo pixel
   static constexpr int Y_BYTES = HH * HW * YP + 64;             // halo image + a zero line for the column groups past the last tap
   static constexpr int LDS = W5_A_BYTES + Y_BYTES;
+  static constexpr int LDS2 = 2 * W5_A_BYTES + Y_BYTES + 2 * W5_CA * 4;  // PA == 3: two images of the 64-channel operand + its constants
   static constexpr int NYL = (HH * HW + NTHREADS - 1) / NTHREADS;  // halo pixels per thread
 };
 
@@ -54,7 +57,58 @@ __device__ __forceinline__ typename TT<T>::vec w5_frag(const w5_u32x2& lo, const
   return __builtin_bit_cast(typename TT<T>::vec, v);
 }
 
-// PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient);
+// The two factors of an activation on one 16-byte slot: relu(bn(x)) = scale (m x) + shift m with m = [f16(fma(x, scale, shift)) > 0]
+// (the forward's own value).  mx = m x is the STORED x or zero - exact, no rounding of its own - and mm = m; `okm` = all ones / zero
+// (the slot's pixel lies inside / outside the image).  k0 scale, k1 shift.
+// f16: mixed-precision fmas on the packed halves and integer mask arithmetic, 4 instructions per element:
+//   d = f16(fma(x, k0, k1))  (2 per pair)    t = min_u16(max_i16(d, 0), 1) & okm: 1 where d > 0 - as integers negative halves and -0
+//   order below +0 - (3)    mm = t * 0x3C00 = 1.0h, mall = t * 0xFFFF (2)    mx = x & mall (1)
+__device__ __forceinline__ void factor_slot(const f16x8& x, const SlotK<8>& k, unsigned okm, f16x8& mx, f16x8& mm) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xi = __builtin_bit_cast(u32x4, x);
+  const unsigned zero2 = 0u, one2 = 0x00010001u, h1 = 0x3C003C00u, all2 = 0xFFFFFFFFu;
+  u32x4 om, ox;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned d, t;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xi[p]), "v"(k.k0[2 * p]), "v"(k.k1[2 * p]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(xi[p]), "v"(k.k0[2 * p + 1]), "v"(k.k1[2 * p + 1]));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(d), "v"(zero2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(one2));
+    t &= okm;
+    unsigned m1, ma;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m1) : "v"(t), "v"(h1));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(ma) : "v"(t), "v"(all2));
+    om[p] = m1;
+    ox[p] = xi[p] & ma;
+  }
+  mx = __builtin_bit_cast(f16x8, ox);
+  mm = __builtin_bit_cast(f16x8, om);
+}
+__device__ __forceinline__ void factor_slot(const bf16x8& x, const SlotK<8>& k, unsigned okm, bf16x8& mx, bf16x8& mm) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xi = __builtin_bit_cast(u32x4, x);
+  u32x4 om, ox;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float lo = __builtin_bit_cast(float, xi[p] << 16), hi = __builtin_bit_cast(float, xi[p] & 0xffff0000u);
+    // (the forward's own rounded value: bn_relu_slot)
+    const bool on0 = okm != 0u && (float)(bf16)fmaf(lo, k.k0[2 * p], k.k1[2 * p]) > 0.f;
+    const bool on1 = okm != 0u && (float)(bf16)fmaf(hi, k.k0[2 * p + 1], k.k1[2 * p + 1]) > 0.f;
+    om[p] = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
+    ox[p] = xi[p] & ((on0 ? 0xFFFFu : 0u) | (on1 ? 0xFFFF0000u : 0u));
+  }
+  mx = __builtin_bit_cast(bf16x8, ox);
+  mm = __builtin_bit_cast(bf16x8, om);
+}
+
+// PA = prologue of the 64-channel operand: 1 BN+ReLU (an activation), 0 none / 2 effective gradient (an output gradient),
+//      3 (round 5, second half) the two FACTORS of the activation on the 64-channel side, relu(bn(x)) = scale (m x) + shift m with
+//      m = [bn(x) > 0]: two LDS images [m x | m] - the stored x itself or zero: no rounding -, two accumulator sets, results to `sbuf`
+//      [2][4][64][32] doubles (variant 0 = S2 = corr(m x, dY), 1 = S1 = corr(m, dY)).  The head's 5x5 convolution `refine1` (reference
+//      M:128-131): its weight gradient dW = scale S2 + shift S1 AND the BatchNorm-backward reductions of norm1, sum dz = sum_{tap,n}
+//      W[n][c][tap] S1[c][tap][n] and sum dz xhat = (sum W S2 - mean sum W S1) invstd (wg5_fin64_kernel) - the reductions-only FIRST
+//      pass of the two-pass data gradient (0.68 ms, one pass over 1.26 GB at C2) is not run any more;
 // PY = prologue of the thin operand: 1 BN+ReLU (the raw-input channels of the head's first convolution sit behind norm0), 0 none,
 //      2 (round 5) the two FACTORS of that activation: relu(bn(x)) = gamma * (m * xhat) + beta * m with m = [bn(x) > 0] and xhat the
 //      normalised input.  The halo pixel holds [m * xhat (8 channels) | m (8 channels)], the kernel correlates both with the output
@@ -67,7 +121,7 @@ template <typename T, int TR, int STR, int PA, int PY>
 __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
-  constexpr int TCOL = PY == 2 ? 16 : 8;
+  constexpr int TCOL = PY == 2 ? 16 : (PA == 3 ? 4 : 8);
   typedef W5Geo<TR, STR, TCOL> G5;
   constexpr int W5_HH = G5::HH, W5_HW = G5::HW, W5_NCH = G5::NCH, NYL = G5::NYL, YP = G5::YP;
   constexpr int SLOT = 8;
@@ -77,8 +131,9 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   const Seg& sa = a.dy;      // A, pixel aligned
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NIMG = PA == 3 ? 2 : 1;
   unsigned char* As = smem;
-  unsigned char* Ys = smem + W5_A_BYTES;
+  unsigned char* Ys = smem + NIMG * W5_A_BYTES;
   constexpr int ZERO = W5_HH * W5_HW * YP;  // offset of the zero line in the dY image
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,6 +146,11 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   ka.k0 = 0.f; ka.k1 = 0.f; ka.k2 = 0.f; ka.k3 = 0.f;
   if (PA == 1) { ka.k0 = load_fv<SLOT>(sa.scale + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.shift + ca * SLOT); }
   if (PA == 2) { ka.k0 = load_fv<SLOT>(sa.q + ca * SLOT); ka.k1 = load_fv<SLOT>(sa.r + ca * SLOT); }
+  // PA == 3: [scale | shift] x 64 in LDS, read where a tile is stored; held in registers across the contraction the constants spill
+  // the two accumulator sets
+  float* kcl = (float*)(smem + NIMG * W5_A_BYTES + G5::Y_BYTES);
+  if (PA == 3 && tid < W5_CA) { kcl[tid] = sa.scale[tid]; kcl[W5_CA + tid] = sa.shift[tid]; }
+  if (PA == 3) __syncthreads();
   const T* asrc = (const T*)sa.src + ca * SLOT;
   const T* asrc2 = (const T*)sa.src2 + ca * SLOT;
   const T* ysrc = (const T*)sy.src;
@@ -147,10 +207,19 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
     for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
+      if constexpr (PA == 3) {
+        SlotK<SLOT> kx;
+        kx.k0 = load_fv<SLOT>(kcl + ca * SLOT); kx.k1 = load_fv<SLOT>(kcl + W5_CA + ca * SLOT); kx.k2 = 0.f; kx.k3 = 0.f;
+        V mx, mm;
+        factor_slot(R.ra[i], kx, ((R.oka >> i) & 1) ? 0xFFFFFFFFu : 0u, mx, mm);
+        *(V*)(As + alds[i]) = mx;
+        *(V*)(As + W5_A_BYTES + alds[i]) = mm;
+      } else {
       V v = R.ra[i];
       if constexpr (PA == 1) v = bn_relu_slot(R.ra[i], ka);
       if constexpr (PA == 2) v = eff_grad_slot(R.ra[i], R.ra2[i], ka);
       *(V*)(As + alds[i]) = ((R.oka >> i) & 1) ? v : z;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NYL; ++i) {
@@ -168,6 +237,13 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
           const bool ok = (R.oky >> i) & 1;
           *(V*)(Ys + hp * YP) = ok ? f32_to_vec<T>(mx) : z;
           *(V*)(Ys + hp * YP + 16) = ok ? f32_to_vec<T>(mm) : z;
+        } else if constexpr (TCOL == 4) {   // the first four channels of the slot only
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x4 yv = __builtin_bit_cast(u32x4, R.ry[i]);
+          const bool ok = (R.oky >> i) & 1;
+          const u32x2 y2 = {ok ? yv[0] : 0u, ok ? yv[1] : 0u};
+          *(u32x2*)(Ys + hp * YP) = y2;
         } else {
           V v = R.ry[i];
           if constexpr (PY == 1) v = bn_relu_slot(R.ry[i], kyk);
@@ -180,11 +256,11 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   // wave w: 64-channel operand rows 32 (w & 1) .., chunks (w >> 1), (w >> 1) + 2, ...
   constexpr int NQ = G5::NQ;
   const int cw = wave & 1, q0 = wave >> 1;
-  f32x16 acc[NQ];
+  f32x16 acc[NQ], acc1[PA == 3 ? NQ : 1];
 #pragma unroll
   for (int m = 0; m < NQ; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[m][i] = 0.f; if (PA == 3) acc1[m][i] = 0.f; }
 
   // transposed-read lane geometry (see wgrad.hip): group tg = lane >> 4 covers columns 16 (tg & 1) .., rows 8 (tg >> 1) + tq (+4)
   const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
@@ -196,8 +272,9 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
   for (int m = 0; m < NQ; ++m) {
     const int q = q0 + 2 * m;
     // TCOL = 8: tap 4 q + 2 (tg & 1) + (tp >> 1), channels 4 (tp & 1) ..; TCOL = 16: tap 2 q + (tg & 1), variant tp >> 1, channels 4 (tp & 1) ..
-    const int tap = TCOL == 8 ? 4 * q + 2 * (tg & 1) + (tp >> 1) : 2 * q + (tg & 1);
-    const int sub = TCOL == 8 ? (tp & 1) * 8 : (tp >> 1) * 16 + (tp & 1) * 8;
+    // TCOL = 4: tap 8 q + 4 (tg & 1) + tp, channels 0 .. 3
+    const int tap = TCOL == 8 ? 4 * q + 2 * (tg & 1) + (tp >> 1) : (TCOL == 4 ? 8 * q + 4 * (tg & 1) + tp : 2 * q + (tg & 1));
+    const int sub = TCOL == 8 ? (tp & 1) * 8 : (TCOL == 4 ? 0 : (tp >> 1) * 16 + (tp & 1) * 8);
     const bool live = q < W5_NCH && tap < sy.ntaps;
     const int tw = sy.taps[live ? tap : 0];
     const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
@@ -211,12 +288,15 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
     for (int ms = 0; ms < W5_TH; ++ms) {  // one tile row = 16 pixels of the contraction per step
       const unsigned char* ap = As + (16 * ms + arow) * 128 + acol;
       const V af = w5_frag<T>(w5_tr16(ap), w5_tr16(ap + 4 * 128));
+      V af1 = af;
+      if constexpr (PA == 3) af1 = w5_frag<T>(w5_tr16(ap + W5_A_BYTES), w5_tr16(ap + W5_A_BYTES + 4 * 128));
 #pragma unroll
       for (int m = 0; m < NQ; ++m) {
         if (q0 + 2 * m < W5_NCH) {  // (wave-uniform)
           const unsigned char* yp = Ys + boff[m] + ms * bstep[m];
           const V bf = w5_frag<T>(w5_tr16(yp), w5_tr16(yp + bsec[m]));
           acc[m] = mma16(af, bf, acc[m]);
+          if constexpr (PA == 3) acc1[m] = mma16(af1, bf, acc1[m]);
         }
       }
     }
@@ -246,7 +326,16 @@ __global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : 2)) void wg5_kernel(const 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * h;
-      atomic_add_f32((PY == 2 ? a.sbuf : a.dpack) + ((size_t)q * a.Npad + c) * 32 + r, acc[m][i]);
+      if constexpr (PA == 3) {
+        // fp64 across workgroups: these sums become BatchNorm-backward reductions of a norm ON the data-gradient chain - with fp32 atomics
+        // (4e-7 of run-to-run noise in a sum) the whole encoder's gradients moved by 3e-3 between two runs (DenseNet-121 amplifies a
+        // per-channel offset of the head's gradient ~1e4-fold); a workgroup's own fp32 accumulation is deterministic and averages out
+        double* dst = (double*)a.sbuf + ((size_t)q * a.Npad + c) * 32 + r;
+        atomic_add_f64(dst, (double)acc[m][i]);
+        atomic_add_f64(dst + (size_t)W5_NCH * a.Npad * 32, (double)acc1[m][i]);
+      } else {
+        atomic_add_f32((PY == 2 ? a.sbuf : a.dpack) + ((size_t)q * a.Npad + c) * 32 + r, acc[m][i]);
+      }
     }
   }
 }
@@ -258,7 +347,7 @@ void wg5_set_enabled(bool on) { g_wg5 = on; }
 template <typename T, int TR, int STR, int PA, int PY = 0>
 static hipError_t launch_wg5_t(const Wg5Args& g, int nwg, hipStream_t st) {
   auto kern = wg5_kernel<T, TR, STR, PA, PY>;
-  constexpr int lds = W5Geo<TR, STR, PY == 2 ? 16 : 8>::LDS;
+  constexpr int lds = PA == 3 ? W5Geo<TR, STR, 4>::LDS2 : W5Geo<TR, STR, PY == 2 ? 16 : 8>::LDS;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), lds, st, g);
   return hipGetLastError();
 }
@@ -280,7 +369,8 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
     return hipErrorNotSupported;
   if (q.nchunks != (q.ntaps * 8 + 31) / 32) return hipErrorNotSupported;
   const bool factors = a.sbuf != nullptr;   // PY = 2: the activation's two factors, results to sbuf
-  if (factors && !(raw3 && a.t_mean != nullptr && a.t_invstd != nullptr)) return hipErrorNotSupported;
+  const bool head5 = !stem && !raw3;
+  if (factors && !((raw3 || head5) && a.t_mean != nullptr && a.t_invstd != nullptr)) return hipErrorNotSupported;
   if (p.mode != G_PLAIN || p.istride != 1 || p.ntaps != 1 || p.taps[0] != 0 || p.C != W5_CA || p.Hs != a.Ho || p.Ws != a.Wo) return hipErrorNotSupported;
   if ((stem || raw3) ? p.scale != nullptr : (p.scale == nullptr || p.q != nullptr)) return hipErrorNotSupported;
   if (a.N != W5_CA || a.Npad != W5_CA) return hipErrorNotSupported;
@@ -313,6 +403,7 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
     if (p.q) return f16t ? launch_wg5_t<f16, 1, 1, 2, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 2, 1>(g, nwg, st);
     return f16t ? launch_wg5_t<f16, 1, 1, 0, 1>(g, nwg, st) : launch_wg5_t<bf16, 1, 1, 0, 1>(g, nwg, st);
   }
+  if (head5 && factors) return f16t ? launch_wg5_t<f16, 2, 1, 3>(g, nwg, st) : launch_wg5_t<bf16, 2, 1, 3>(g, nwg, st);
   if (!stem) return f16t ? launch_wg5_t<f16, 2, 1, 1>(g, nwg, st) : launch_wg5_t<bf16, 2, 1, 1>(g, nwg, st);
   if (p.q) return f16t ? launch_wg5_t<f16, 3, 2, 2>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 2>(g, nwg, st);
   return f16t ? launch_wg5_t<f16, 3, 2, 0>(g, nwg, st) : launch_wg5_t<bf16, 3, 2, 0>(g, nwg, st);
@@ -349,6 +440,50 @@ __global__ __launch_bounds__(256) void wg5_rawfin_kernel(const RawFinArgs a) {
 hipError_t launch_wg5_rawfin(const RawFinArgs& a, hipStream_t st) {
   if (g_ctl.dry) return hipSuccess;
   hipLaunchKernelGGL(wg5_rawfin_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// From the factor correlations of the 64-channel operand (wg5_kernel, PA = 3; sbuf [2][4][64 c][32] DOUBLES, column 32 chunk + k =
+// 4 tap + n, variant 0 = S2 = corr(m x, dY), 1 = S1 = corr(m, dY)) to
+//   * the packed weight gradient of the 5x5 convolution, dP[(8 tap + n) / 32][c][(8 tap + n) % 32] += scale[c] S2 + shift[c] S1
+//     (relu(bn(x)) = scale (m x) + shift m), and
+//   * norm1's BatchNorm-backward reductions (fp64): red1[c] += sum_{tap,n} W[n][c][tap] S1[c][tap][n] = sum dz,
+//     red2[c] += (sum W S2 - mean[c] sum W S1) invstd[c] = sum dz xhat - what the reductions-only pass of the 5x5 data gradient
+//     computed from dz = m * (sum_{tap,n} W dY).
+// Eight workgroups of 8 channels: 32 threads share a channel's 100 columns (a one-workgroup form took 31 us: 50 dependent rounds).
+__global__ __launch_bounds__(256) void wg5_fin64_kernel(const Fin64Args a) {
+  const int tid = threadIdx.x, c = blockIdx.x * 8 + (tid >> 5), part = tid & 31;
+  const double sc = (double)a.scale[c], sh = (double)a.shift[c];
+  const double* sb = (const double*)a.sbuf;
+  double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = part + 32 * u;   // = chunk u, column `part`
+    if (j >= 100) break;
+    const size_t at = ((size_t)u * 64 + c) * 32 + part;
+    const double s2 = sb[at], s1 = sb[(size_t)4 * 64 * 32 + at];
+    const int n = j & 3, tap = j >> 2, jp = 8 * tap + n;
+    a.dpack[((size_t)(jp >> 5) * a.Npad + c) * 32 + (jp & 31)] += (float)(sc * s2 + sh * s1);
+    if (n < a.nreal) {
+      // the weight the data gradient's STORING pass multiplies with: the master weight rounded to the storage type (pack).  With the
+      // fp32 master the two sums were those of a slightly different dz than the one stored (6e-5 of a sum - 3e-3 on conv0's gradient)
+      const float wm = a.w[((size_t)n * a.Kin + c) * 25 + a.tapw[tap]];
+      const double w = a.dtype == DT_F16 ? (double)(float)(f16)wm : (double)(float)(bf16)wm;
+      r1 += w * s1;
+      r2 += w * s2;
+    }
+  }
+#pragma unroll
+  for (int s = 1; s < 32; s <<= 1) { r1 += __shfl_xor(r1, s); r2 += __shfl_xor(r2, s); }
+  if (part == 0) {   // (replica 0; this launch is the only writer of these channels)
+    a.red1[c] += r1;
+    a.red2[c] += (r2 - (double)a.mean[c] * r1) * (double)a.invstd[c];
+  }
+}
+
+hipError_t launch_wg5_fin64(const Fin64Args& a, hipStream_t st) {
+  if (g_ctl.dry) return hipSuccess;
+  hipLaunchKernelGGL(wg5_fin64_kernel, dim3(8), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

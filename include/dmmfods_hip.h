@@ -211,6 +211,15 @@ int dmm_conv_wgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, con
 int dmm_conv_dgrad_ex(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
                       const void* yfwd, const float* q, const float* r, void* gx, int accumulate, double* red, void* scratch,
                       void* stream);
+/* The head's last convolution (5x5, 64 channels onto <= 4 classes behind BatchNorm2d + ReLU; reference
+ * graphs/models/Dense_U_Net_lidar.py:128-131), 16-bit storage: its weight gradient AND the BatchNorm-backward reductions of the norm
+ * in front of it - red[0..64) = sum dz, red[64..128) = sum dz*xhat over all pixels, dz = relu'(x*scale+shift) * conv_dgrad(dy) with
+ * the weights rounded to the storage type, as dmm_conv_dgrad reports them - from ONE pass over x and dy (wg5.hip, PA = 3: x enters as
+ * the two factors of its activation; wg5_fin64_kernel).  w: fp32 master weights (Cout, 64, 5, 5); `shift` points at 3*64 floats:
+ * shift, mean, invstd; dw: fp32, master layout, overwritten; red: 128 doubles, zeroed by the callee.  DMM_ERR_INVALID for any other
+ * shape.  (Nothing upstream: autograd runs conv2d's and batch_norm's backward as separate ATen calls.) */
+int dmm_conv5_wgrad_stats(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale, const float* shift,
+                          float* dw, double* red, void* scratch, void* stream);
 /* Data gradient AND weight gradient of a 1x1 bottleneck convolution in one pass (bw1.hip; 16-bit storage, Cout == 128,
  * Cin % 32 == 0; DMM_ERR_INVALID otherwise): the two results of dmm_conv_dgrad_ex and dmm_conv_wgrad_ex on the same operands. */
 int dmm_conv1x1_backward_fused(const dmm_conv_desc* d, const void* x, const void* dy, const float* w, const float* scale,

@@ -234,6 +234,7 @@ HOST_DRIVE_CASES = [
     ("d121e", "f16", 2, 64, 96, {}),
     ("d121e", "f16", 2, 64, 96, {"DMM_NO_HF": "1"}),
     ("d121e", "bf16", 2, 64, 96, {"DMM_NO_RAW_STATS": "1"}),
+    ("d121e", "f16", 2, 64, 96, {"DMM_NO_R1_STATS": "1"}),
     ("d121e", "f16", 2, 64, 96, {"DMM_NO_HF": "1", "DMM_NO_C3_MERGE": "1", "DMM_NO_CVP_MERGE": "1", "DMM_NO_WGP_MERGE": "1"}),
     ("d121e", "f16", 2, 64, 96, {"DMM_DEFER_WGRAD": "1", "DMM_NO_WGP_MERGE": "1"}),
     ("d121m", "f16", 2, 128, 192, {}),

@@ -329,7 +329,9 @@ def test_two_pass_batchnorm_backward_of_the_head(dtype, tol, monkeypatch):
     """Round 4: the data gradient of the head's 5x5 convolution runs twice - reductions only, then (the correction constants of the
     BatchNorm in front of it being final) storing s*dz + q + r*x - instead of once plus an apply_corr pass over the 64-channel
     full-resolution gradient.  Against the one-pass + apply_corr schedule (DMM_NO_TWO_PASS=1): the same gradients up to ONE 16-bit
-    rounding of that tensor (the old schedule rounds s*dz, then the corrected sum)."""
+    rounding of that tensor (the old schedule rounds s*dz, then the corrected sum).  (Round 5 took the FIRST of the two passes away
+    again - norm1's sums come from the 5x5 weight gradient, test_head_norm1_batchnorm_sums_from_the_5x5_weight_gradient -; this test
+    pins the two-pass form itself, DMM_NO_R1_STATS=1.)"""
     from oracle import restatement as R
     arch = R.Arch(growth_rate=32, block_config=(1, 1), num_init_features=64, concat_before_block_num=1, stream_2_in_channels=3)
     model = _model(arch, dtype)
@@ -337,6 +339,7 @@ def test_two_pass_batchnorm_backward_of_the_head(dtype, tol, monkeypatch):
     model = model.to(DEV).train()
     rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 64, 96, seed=3))
     grads, labels = {}, {}
+    monkeypatch.setenv("DMM_NO_R1_STATS", "1")
     for off in (0, 1):
         if off:
             monkeypatch.setenv("DMM_NO_TWO_PASS", "1")
@@ -349,6 +352,7 @@ def test_two_pass_batchnorm_backward_of_the_head(dtype, tol, monkeypatch):
         labels[off] = plan_labels(model._last[0])
         grads[off] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     monkeypatch.delenv("DMM_NO_TWO_PASS", raising=False)
+    monkeypatch.delenv("DMM_NO_R1_STATS", raising=False)
     model.close()
     n_on = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[0])
     n_off = sum(lab.startswith("conv3.bnbwd") and lab.endswith("h.refine1") for lab in labels[1])
@@ -474,6 +478,68 @@ def test_raw_input_batchnorm_sums_from_the_weight_gradient(dtype, tol, monkeypat
     assert float((a - b).norm() / b.norm()) < tol, float((a - b).norm() / b.norm())
     for k in grads[0]:
         assert _rel(grads[0][k], grads[1][k]) < max(tol, 2e-3), k
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_conv5_weight_gradient_and_batchnorm_sums_in_one_pass(dtype):
+    """Round 5: dmm_conv5_wgrad_stats (wg5.hip PA = 3 + wg5_fin64_kernel) against fp64 torch on the same 16-bit operands - the weight
+    gradient of the head's 5x5 convolution and norm1's two BatchNorm-backward sums, the latter to 1e-6 of the largest channel sum
+    (fp32 accumulation per workgroup, fp64 across workgroups; the sums sit on the data-gradient chain).  Shapes: several tiles per
+    workgroup, a ragged picture, four classes."""
+    from tools import gpu_lab as lab
+    assert lab.conv5_stats_case("5x5 64->3", dtype, 2, 24, 40)
+    assert lab.conv5_stats_case("5x5 64->3 ragged", dtype, 1, 13, 21, seed=1)
+    assert lab.conv5_stats_case("5x5 64->4 @96x160", dtype, 2, 96, 160, Cout=4, seed=2)
+    assert lab.conv5_stats_case("5x5 64->3 @320x480", dtype, 2, 320, 480, seed=3, ref_dev="cuda")
+
+
+@pytest.mark.parametrize("dtype,tol_n,tol_w,tol_all", [("fp16", 5e-5, 2e-4, 3e-3), ("bf16", 5e-4, 2e-3, 2e-2)])
+def test_head_norm1_batchnorm_sums_from_the_5x5_weight_gradient(dtype, tol_n, tol_w, tol_all, monkeypatch):
+    """Round 5: the head's last convolution (5x5, 64 -> classes; reference M:128-131) sits behind norm1 + ReLU, so its backward needs
+    sum dz and sum dz * xhat of dz = m * (W^T dY) over the full-resolution map BEFORE the gradient towards refine0 can be stored - the
+    two-pass data gradient ran a reductions-only first pass over the 64-channel activation for them.  The weight gradient of the same
+    convolution reads the same activation and the same logits gradient: with the activation entered as its two factors,
+    relu(bn(x)) = scale (m x) + shift m, the launch (wg5.hip, PA = 3) yields S2 = corr(m x, dY) and S1 = corr(m, dY), and a small
+    launch derives dW = scale S2 + shift S1 AND both sums (sum dz = sum W S1, sum dz xhat = (sum W S2 - mean sum W S1) invstd).
+    Against the two-pass path (DMM_NO_R1_STATS=1): the launch list holds the finish launch and ONE 5x5 data-gradient pass instead of
+    two; norm1's gamma / beta gradients (= the two sums) and refine1's weight gradient agree to 3e-6 / 2e-5 in f16 (measured) - the
+    distance is the OLD path's: its epilogue stages dz in 16 bits before summing (3e-6 of a sum in f16, 3e-5 in bf16), while the new
+    sums are within 4e-8 of fp64 (test_conv5_weight_gradient_and_batchnorm_sums_in_one_pass).  Everything else in the network sits
+    behind norm1's backward, and DenseNet-121 amplifies a per-channel offset of the head's gradient ~1e3-fold on the way to conv0:
+    global relative L2 over all gradients 6e-4 (f16) / 5e-3 (bf16) measured; both paths are bit-reproducible run to run
+    (tools/probes/r05_r1stats.py)."""
+    from oracle import restatement as R
+    arch = R.densenet_arch(121, concat_before_block_num=1, stream_2_in_channels=3)
+    model = _model(arch, dtype)
+    model.load_state_dict(R.make_state(arch, seed=29))
+    model = model.to(DEV).train()
+    rgb, lidar, tgt = (t.to(DEV) for t in R.make_inputs(arch, 2, 96, 160, seed=5))
+    grads, labs = {}, {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("DMM_NO_R1_STATS", "1")
+        else:
+            monkeypatch.delenv("DMM_NO_R1_STATS", raising=False)
+        model.close()
+        model(rgb, lidar)
+        model.loss_backward(tgt)
+        torch.cuda.synchronize()
+        labs[off] = plan_labels(model._last[0], lists=(1,))
+        grads[off] = {k: p.grad.detach().double().cpu().clone() for k, p in model.named_parameters()}
+    monkeypatch.delenv("DMM_NO_R1_STATS", raising=False)
+    model.close()
+    assert sum(lab.startswith("wg5.fin64") for lab in labs[0]) == 1 and not any(lab.startswith("wg5.fin64") for lab in labs[1])
+    passes = [sum("conv3.bnbwd.n64/h.refine1" in lab for lab in labs[o]) for o in (0, 1)]
+    assert passes == [1, 2], (passes, [l for l in labs[0] if "refine1" in l])
+    for k, tol in (("dec_out_to_heat_maps.norm1.weight", tol_n), ("dec_out_to_heat_maps.norm1.bias", tol_n),
+                   ("dec_out_to_heat_maps.refine1.weight", tol_w)):
+        a, b = grads[0][k], grads[1][k]
+        assert float(b.abs().max()) > 0
+        assert float((a - b).norm() / b.norm()) < tol, (k, float((a - b).norm() / b.norm()))
+    num = sum(float((grads[0][k] - grads[1][k]).pow(2).sum()) for k in grads[0])
+    den = sum(float(grads[1][k].pow(2).sum()) for k in grads[0])
+    assert (num / den) ** 0.5 < tol_all, (num / den) ** 0.5
+    assert all(torch.isfinite(v).all() for v in grads[0].values())
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])

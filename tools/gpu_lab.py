@@ -206,6 +206,52 @@ def backward_case(name, dtype, B, H, W, Cin, Cout, R, S, pad, transposed=0, with
     return not bad and fam_ok
 
 
+def conv5_stats_case(name, dtype, B, H, W, Cout=3, seed=0, ref_dev="cpu"):
+    """dmm_conv5_wgrad_stats (round 5; wg5.hip PA = 3 + wg5_fin64_kernel): the head's 5x5 convolution behind BN+ReLU - weight gradient
+    AND the two BatchNorm-backward sums of the norm in front of it from one pass over x and dy - against fp64 torch on the same
+    16-bit-rounded operands: dz = [bn(x) > 0] * conv_dgrad(dy, w rounded to the storage type).  The sums are held to 1e-6 (f16) of the
+    largest channel sum: they feed a norm ON the data-gradient chain, where a per-channel offset is amplified ~1e4-fold by the
+    encoder behind it (the data-gradient pass these sums used to come from staged dz in 16 bits: 3e-6 / 3e-5 off)."""
+    g = torch.Generator(device=ref_dev).manual_seed(seed)
+    dt = {1: torch.float16, 2: torch.bfloat16}[dtype]
+    kw = dict(generator=g, device=ref_dev)
+    Cin = 64
+    x = torch.randn(B, Cin, H, W, **kw) * 2 + 0.5
+    scale = torch.rand(Cin, **kw) + 0.5
+    shift = torch.randn(Cin, **kw) * 0.5
+    mean = torch.randn(Cin, **kw)
+    invstd = torch.rand(Cin, **kw) + 0.5
+    w = torch.randn(Cout, Cin, 5, 5, **kw) / (Cin * 25) ** 0.5
+    dy = torch.rand(B, Cout, H, W, **kw) - 0.3            # like sigmoid(logit) - target: a non-zero mean
+    xq, dyq, wq = x.to(dt).double(), dy.to(dt).double(), w.to(dt).double()
+    z = xq.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)       # the forward's own fp32 fma ...
+    m = (z.to(dt).float() > 0).double()                                       # ... rounded to the storage type, then ReLU
+    a = m * (xq * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))   # scale (m x) + shift m: the activation, unrounded
+    dz = m * F.conv_transpose2d(dyq, wq, padding=2)                           # conv_dgrad of a unit-stride conv = conv_transpose
+    xhat = (xq - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    red1_ref, red2_ref = dz.sum(dim=(0, 2, 3)), (dz * xhat).sum(dim=(0, 2, 3))
+    wr = wq.clone().requires_grad_(True)
+    (F.conv2d(a, wr, padding=2) * dyq).sum().backward()
+    dw_ref = wr.grad
+    d = _lib.ConvDesc(dtype=dtype, use_mfma=1, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=5, S=5, stride=1, pad=2, transposed=0, mode=0, bn_relu=1)
+    scratch = torch.zeros(L.dmm_conv_scratch_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+    xd, dyd = nhwc(x, dt).to(DEV), nhwc(dy, dt).to(DEV)
+    wd, sd, hd = w.to(DEV), scale.to(DEV), torch.cat([shift, mean, invstd]).to(DEV)
+    red = torch.full((2 * Cin,), float("nan"), dtype=torch.float64, device=DEV)
+    dwd = torch.full((Cout, Cin, 5, 5), float("nan"), device=DEV)
+    _lib.impls_since_reset()
+    _lib.check(L.dmm_conv5_wgrad_stats(C.byref(d), xd.data_ptr(), dyd.data_ptr(), wd.data_ptr(), sd.data_ptr(), hd.data_ptr(), dwd.data_ptr(),
+                                       red.data_ptr(), scratch.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    fam_ok = _check_family(f"conv5 {name}", "wg5")
+    res = {"red1": relerr(red[:Cin].cpu(), red1_ref.cpu()), "red2": relerr(red[Cin:].cpu(), red2_ref.cpu()),
+           "wgrad": relerr(dwd.cpu(), dw_ref.cpu())}
+    tol = {"red1": 1e-6, "red2": 1e-6, "wgrad": {1: 3e-3, 2: 2.5e-2}[dtype]}
+    bad = [k for k, v in res.items() if not (v < tol[k])]
+    print(f"{'FAIL' if bad else 'ok  '} conv5  {name:28s} dt={dtype} " + " ".join(f"{k}={v:.2e}" for k, v in res.items()), flush=True)
+    return not bad and fam_ok
+
+
 def production_forward_case(name, dtype, B, H, W, Cin, Cout, R, stride, pad, bn, transposed=0, reps=3, expect=None):
     """A forward convolution at a PRODUCTION size through the C ABI, several times on identical operands: against torch's GPU
     convolution (fp32 on the same 16-bit-rounded operands) and run to run (bitwise).  Timing-dependent hazards of the LDS pipelines

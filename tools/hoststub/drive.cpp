@@ -79,6 +79,7 @@ void chk_ops(const std::vector<Op>& ops) {
       case OP_BCE: CHK(o.bce.logits); CHK(o.bce.target); CHK(o.bce.dlogits); CHK(o.bce.out); CHK(o.bce.loss_out); CHK(o.bce.dx_out); break;
       case OP_PACK: case OP_UNPACK: CHK(o.pk.descs); CHK(o.pk.prefix); CHK(o.pk.tdescs); CHK(o.pk.tiles); break;
       case OP_APPLYCORR: CHK(o.ac.g); CHK(o.ac.y); CHK(o.ac.q); CHK(o.ac.r); CHK(o.ac.ql); CHK(o.ac.rl); break;
+      case OP_FIN64: CHK(o.f64.sbuf); CHK(o.f64.dpack); CHK(o.f64.w); CHK(o.f64.scale); CHK(o.f64.shift); CHK(o.f64.mean); CHK(o.f64.invstd); CHK(o.f64.red1); CHK(o.f64.red2); break;
       case OP_RAWFIN: CHK(o.rf.sbuf); CHK(o.rf.dpack); CHK(o.rf.w); CHK(o.rf.gamma); CHK(o.rf.beta); CHK(o.rf.red1); CHK(o.rf.red2); break;
       case OP_JOIN: break;
       default: ++g_bad; fprintf(stderr, "[drive] unknown op kind %d\n", o.kind);
