@@ -379,6 +379,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
     grads, labels = {}, {}
     monkeypatch.setenv("DMM_NO_WGP_MERGE", "1")     # (held-back phase launches are not merged into one: compare like with like)
     monkeypatch.setenv("DMM_NO_RAW_STATS", "1")     # (nor does a held-back raw-segment weight gradient feed the norm's sums: round 5)
+    monkeypatch.setenv("DMM_NO_R1_STATS", "1")      # (nor the held-back 5x5 weight gradient norm1's: the data-gradient chain would wait for it)
     for off in (0, 1):
         if off:
             monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
@@ -393,6 +394,7 @@ def test_deferred_head_and_decoder_weight_gradients(monkeypatch):
     monkeypatch.delenv("DMM_DEFER_WGRAD", raising=False)
     monkeypatch.delenv("DMM_NO_WGP_MERGE", raising=False)
     monkeypatch.delenv("DMM_NO_RAW_STATS", raising=False)
+    monkeypatch.delenv("DMM_NO_R1_STATS", raising=False)
     model.close()
     assert sorted(labels[0]) == sorted(labels[1])
     first_head_w = {o: next(i for i, lab in enumerate(labels[o]) if lab.startswith(("wgp.", "wg5.")) and "/h." in lab) for o in (0, 1)}
