@@ -20,7 +20,7 @@ namespace dmm {
 
 constexpr int W5_TH = 8, W5_TW = 16;
 #ifndef W5_F_PER_CU
-#define W5_F_PER_CU 3   // workgroups per CU of the factor form (PA = 3): 166 registers fit three waves per SIMD (lab: -DW5_F_PER_CU=2)
+#define W5_F_PER_CU 3   // workgroups per CU of the factor forms (PA = 3: 166 registers; PA = 0, PY = 2: 154): three waves per SIMD (lab: -DW5_F_PER_CU=2)
 #endif
 constexpr int W5_CA = 64;
 constexpr int W5_A_BYTES = BM * W5_CA * 2;                    // 16 KB, 128-byte rows, 64-byte granule XOR-ed with (row >> 1) & 1
@@ -121,7 +121,7 @@ __device__ __forceinline__ void factor_slot(const bf16x8& x, const SlotK<8>& k, 
 //      full-resolution data gradient towards the raw input (0.69 ms, one more pass over the 1.26 GB gradient at C2) existed only for
 //      those two sums per channel.
 template <typename T, int TR, int STR, int PA, int PY>
-__global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : (PA == 3 ? W5_F_PER_CU : 2))) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
+__global__ __launch_bounds__(NTHREADS, (TR == 3 ? 1 : ((PA == 3 || (PA == 0 && PY == 2)) ? W5_F_PER_CU : 2))) void wg5_kernel(const Wg5Args g) {  // (the stem form: 7 accumulator tiles + two operand sets)
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
   constexpr int TCOL = PY == 2 ? 16 : (PA == 3 ? 4 : 8);
@@ -394,7 +394,8 @@ hipError_t launch_wg5(const WgradArgs& a, int dtype, hipStream_t st) {
                               return (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   static const int per_cu = lab_int("DMM_WG5_PER_CU", 2);
   // every workgroup ends with 57 (stem: 106) KB of atomics; a tile costs ~1 us: two workgroups per CU unless the picture is small
-  int nwg = std::max(1, std::min((stem ? 1 : (head5 && factors ? W5_F_PER_CU : per_cu)) * cus, g.ntiles / 8));  // (the stem form holds one workgroup per CU)
+  const bool three = (head5 && factors) || (raw3 && factors && !p.q);
+  int nwg = std::max(1, std::min((stem ? 1 : (three ? W5_F_PER_CU : per_cu)) * cus, g.ntiles / 8));  // (the stem form holds one workgroup per CU)
   g.tiles_per_wg = (g.ntiles + nwg - 1) / nwg;
   nwg = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
   const bool f16t = dtype == DT_F16;
