@@ -508,6 +508,225 @@ __global__ __launch_bounds__(NTHREADS, 2) void cvd_kernel(const CvdArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// cvd_kernel<T, 64, true> - the head's stride-2 data gradient (the 3x3 convolution over the nearest-x2 upsampled decoder output,
+// reference M:120, M:126-127; 16 merged taps over the 64-channel full-resolution gradient) - at THREE workgroups per CU (round 5).
+// Measured: the stretches of a one-tile workgroup add up (halo wait, 16 weight stages with a barrier each, fp32 staging, the
+// epilogue's dependent loads) and neither the weight stream nor the bytes bound it (a tile twice as wide under one weight walk took
+// twice as long, ablations.txt); what hides such stretches is another resident workgroup - a third one was worth 20-25 % on both
+// factor forms of wg5.hip.  cvd_kernel holds two: 76.5 KB of LDS (a halo image sized for 128-channel groups, fp32 staging of the whole
+// 128 x 128 tile) and 202 registers (the epilogue's x / old-gradient rows prefetched under the staging).  Here:
+//   * the halo image of the 64-channel gradient is 153 pixels x 128 bytes WITHOUT the padding slot: slot s of halo pixel p sits at
+//     p * 128 + ((s ^ ((p >> 1) & 7)) << 4) - the 16 pixels of a fragment read (consecutive p) hit 16 different 16-byte slots of the
+//     256-byte bank period: the two parities of p take the halves, (p >> 1) & 7 permutes the slots inside a half -, 19.1 KB;
+//   * the fp32 staging runs in two column halves of 64 (34.8 KB over the dead images) with the epilogue of a half behind each;
+//   * no prefetch across the staging: <= 168 registers.
+// 52.9 KB of LDS: three workgroups per CU.  Same K order and epilogue arithmetic per output element as cvd_kernel: gradients
+// bit-equal, the BatchNorm sums equal up to the grouping of their fp32 partials (rows per thread: 4 instead of 8).
+constexpr int C3D_NHP = CP_HH * CP_HW;                       // 153 halo pixels
+constexpr int C3D_X_BYTES = C3D_NHP * 128;                   // 19 584
+constexpr int C3D_MAIN = C3D_X_BYTES + 2 * CP_B_STAGE;       // 52 352
+constexpr int C3D_LDS = C3D_MAIN + BM * 4;                   // + rowpix
+constexpr int C3D_FP = 64 + 4;                               // staging pitch (floats) of a column half
+constexpr int C3D_RED = BM * C3D_FP * 4;                     // offset of the fp64 sums inside the dead images
+static_assert(C3D_RED + 2 * 128 * 8 <= C3D_MAIN, "staging of a column half + the fp64 sums fit the operand images");
+static_assert(3 * C3D_LDS <= 160 * 1024, "three workgroups per CU");
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  typedef typename TT<T>::vec V;
+  constexpr int SLOT = 8, BN = CP_BN, NT = BN / 32;
+  constexpr int CSL = 8, PSTEP = NTHREADS / CSL;           // 8 slot columns of a halo pixel, 32 halo pixels between a thread's slots
+  constexpr int NX = (C3D_NHP + PSTEP - 1) / PSTEP;        // 5
+  const ConvArgs& a = g.c;
+  const Seg& sy = a.seg[0];  // dY (materialised gradient), 16 merged taps at stride 2
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Xs = smem;
+  unsigned char* Bs = smem + C3D_X_BYTES;
+  int* rowpix = (int*)(smem + C3D_MAIN);
+  double* red = (double*)(smem + C3D_RED);  // [2 halves][16 values][8 slot columns] fp64; zeroed after the K loop
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = lbid % g.ntn;
+  int tile = lbid / g.ntn;
+  const int tx_i = tile % g.tiles_x; tile /= g.tiles_x;
+  const int ty_i = tile % g.tiles_y;
+  const int b = tile / g.tiles_y;
+  const int y0 = ty_i * CP_TH, x0 = tx_i * CP_TW, n0 = ntile * BN;
+
+  if (tid < BM) {
+    const int y = y0 + (tid >> 4), x = x0 + (tid & 15);
+    rowpix[tid] = (y < a.Ho && x < a.Wo) ? (b * a.Hout + y) * a.Wout + x : -1;
+  }
+  const int cx = tid % CSL, px0 = tid / CSL;
+  const T* ysrc = (const T*)sy.src + cx * SLOT;
+  V rx[NX];
+  // class (pa, pb): sub-grid pixel (y', x') = dY[2 y' + pa, 2 x' + pb]; its halo starts at (y0 - pa, x0 - pb)
+  auto issue_halo = [&](int pa, int pb, unsigned& ok) {
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hp = px0 + PSTEP * i;
+      const int hy = hp / CP_HW, hx = hp - hy * CP_HW;
+      const int y = 2 * (y0 - pa + hy) + pa, x = 2 * (x0 - pb + hx) + pb;
+      if (hp < C3D_NHP && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws) ok |= 1u << i;
+      const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
+      rx[i] = *(const V*)(ysrc + pix * sy.ld);
+    }
+  };
+  auto store_halo = [&](unsigned ok) {
+    V z;
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) z[e] = (T)0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hp = px0 + PSTEP * i;
+      if (hp < C3D_NHP) *(V*)(Xs + hp * 128 + ((cx ^ ((hp >> 1) & 7)) << 4)) = ((ok >> i) & 1) ? rx[i] : z;
+    }
+  };
+
+  const T* wp = (const T*)a.wpack;
+  const int cpt = sy.Cpad / 32;
+  V rb[2][2];
+  int blds[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = tid + NTHREADS * j, row = piece >> 2, slot = piece & 3;
+    blds[j] = row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+  }
+  auto issue_b = [&](int tap) {
+    const int c0 = tap * cpt;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const T* src = wp + ((size_t)(c0 + uu) * a.Npad + n0) * 32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb[uu][j] = *(const V*)(src + (size_t)(tid + NTHREADS * j) * SLOT);
+    }
+  };
+  auto store_b = [&](int buf) {
+    unsigned char* B = Bs + buf * CP_B_STAGE;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *(V*)(B + uu * (BN * 64) + blds[j]) = rb[uu][j];
+  };
+
+  const int hpl = (2 * wave + (r >> 4)) * CP_HW + (r & 15);   // this lane's halo pixel of tap (0, 0)
+  const int bsw = (r >> 2) & 3;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // flat walk: class -> tap of the class (one stage of 2 chunks = the 64 channels).  Stage s of the walk uses B buffer s & 1.
+  int buf = 0;
+  unsigned ok_cur = 0;
+  issue_halo(0, 0, ok_cur);
+  issue_b(g.tapidx[0]);
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pa = cls >> 1, pb = cls & 1;
+    store_halo(ok_cur);
+    if (cls < 3) issue_halo((cls + 1) >> 1, (cls + 1) & 1, ok_cur);   // the next class's halo flies under this class's stages
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int tap = g.tapidx[4 * cls + tt];
+      const int tw = sy.taps[tap];
+      const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
+      // halo pixel of the tap inside the class: row offset (dy + pa) / 2, likewise the column
+      const int hpt = hpl + ((dy + pa) >> 1) * CP_HW + ((dx + pb) >> 1);
+      const unsigned char* A = Xs + hpt * 128;
+      const int asw = (hpt >> 1) & 7;
+      store_b(buf);
+      __syncthreads();
+      if (4 * cls + tt + 1 < 16) issue_b(g.tapidx[4 * cls + tt + 1]);   // next stage's weights
+      const unsigned char* B = Bs + buf * CP_B_STAGE;
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const V av = *(const V*)(A + (((uu * 4 + s * 2 + h) ^ asw) << 4));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const V bv = *(const V*)(B + (uu * BN + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
+            acc[t] = mma16(av, bv, acc[t]);
+          }
+        }
+      buf ^= 1;
+    }
+    __syncthreads();  // every wave is done with this halo image
+  }
+
+  // ---- epilogue in two column halves: fused BN+ReLU backward (see cvd_kernel / igemm.hip) ----
+  constexpr int NCV = 64 / SLOT, RPP = NTHREADS / NCV, NIT = BM / RPP;   // 8 slot columns x 32 row phases, 4 rows per thread
+  const int cv = tid % NCV, rr = tid / NCV;
+  if (tid < 2 * 128) red[tid] = 0.0;  // (the K loop ended with a barrier: the images are dead)
+  float* Cs = (float*)smem;  // fp32 staging: the ReLU mask and the reductions see the unrounded gradient
+  const T* bx = (const T*)a.bx;
+  T* gout = (T*)a.out;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    if (ch) __syncthreads();  // the first half's staging has been read
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+        Cs[row * C3D_FP + 32 * tt + r] = acc[2 * ch + tt][i];
+      }
+    __syncthreads();
+    const int n = n0 + 64 * ch + cv * SLOT;
+    const bool colvalid = n < a.N;
+    float s1[SLOT], s2[SLOT], sc[SLOT], sh[SLOT], mu[SLOT], is[SLOT];
+#pragma unroll
+    for (int e = 0; e < SLOT; ++e) { s1[e] = 0.f; s2[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+    if (colvalid) {
+      load_f32s<SLOT>(a.bscale + n, sc); load_f32s<SLOT>(a.bshift + n, sh);
+      load_f32s<SLOT>(a.bmean + n, mu); load_f32s<SLOT>(a.binvstd + n, is);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int row = rr + RPP * i;
+      const int pix = colvalid ? rowpix[row] : -1;
+      if (pix < 0) continue;
+      const V xv = *(const V*)(bx + (size_t)pix * a.ldbx + n);
+      V gv;
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) gv[e] = (T)0;
+      if (a.accumulate) gv = *(const V*)(gout + (size_t)pix * a.ldo + n);
+      float av[SLOT], xf[SLOT], gf[SLOT];
+#pragma unroll
+      for (int e = 0; e < SLOT; e += 4) {
+        const f32x4 t4 = *(const f32x4*)(Cs + row * C3D_FP + cv * SLOT + e);
+        av[e] = t4[0]; av[e + 1] = t4[1]; av[e + 2] = t4[2]; av[e + 3] = t4[3];
+      }
+      vec_to_f32<T>(xv, xf);
+      vec_to_f32<T>(gv, gf);  // zeros unless accumulating
+#pragma unroll
+      for (int e = 0; e < SLOT; ++e) {
+        const float dz = (fmaf(xf[e], sc[e], sh[e]) > 0.f) ? av[e] : 0.f;
+        s1[e] += dz;
+        s2[e] = fmaf(dz, (xf[e] - mu[e]) * is[e], s2[e]);
+        gf[e] += sc[e] * dz;
+      }
+      *(V*)(gout + (size_t)pix * a.ldo + n) = f32_to_vec<T>(gf);
+    }
+    fold_to_lds<NCV, SLOT, 64>(s1, s2, red + ch * 128, cv, colvalid, lane);
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < a.N) {
+    const size_t rep = (size_t)(blockIdx.x & (STAT_REPS - 1)) * a.stat_stride;
+    const double* rh = red + (tid >> 6) * 128;
+    atomic_add_f64(a.red1 + rep + n0 + tid, rh[fold_slot<NCV, SLOT>(0, tid & 63)]);
+    atomic_add_f64(a.red2 + rep + n0 + tid, rh[fold_slot<NCV, SLOT>(1, tid & 63)]);
+  }
+}
+
 static bool g_cvp = !lab_flag("DMM_NO_CVP");
 void cvp_set_enabled(bool on) { g_cvp = on; }
 
@@ -619,6 +838,19 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   return x.ntaps == 4 ? launch_cvp_t<bf16, 4>(g, nwg, st) : (x.ntaps == 2 ? launch_cvp_t<bf16, 2>(g, nwg, st) : launch_cvp_t<bf16, 1>(g, nwg, st));
 }
 
+template <typename T>
+static hipError_t launch_cvd3_t(const CvdArgs& g, int nwg, hipStream_t st) {
+  auto kern = cvd3_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C3D_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), C3D_LDS, st, g);
+  return hipGetLastError();
+}
+
 template <typename T, int CA, bool UP2>
 static hipError_t launch_cvd_t(const CvdArgs& g, int nwg, hipStream_t st) {
   auto kern = cvd_kernel<T, CA, UP2>;
@@ -659,6 +891,8 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
   g.tiles_x = (a.Wo + CP_TW - 1) / CP_TW;
   g.ntn = a.Npad / CP_BN;
   const int nwg = a.B * g.tiles_y * g.tiles_x * g.ntn;
+  static const bool three = !lab_flag("DMM_NO_CVD3");
+  if (up2 && three) return dtype == DT_F16 ? launch_cvd3_t<f16>(g, nwg, st) : launch_cvd3_t<bf16>(g, nwg, st);
   if (up2) return dtype == DT_F16 ? launch_cvd_t<f16, 64, true>(g, nwg, st) : launch_cvd_t<bf16, 64, true>(g, nwg, st);
   return dtype == DT_F16 ? launch_cvd_t<f16, 128, false>(g, nwg, st) : launch_cvd_t<bf16, 128, false>(g, nwg, st);
 }
