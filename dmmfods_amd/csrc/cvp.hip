@@ -532,7 +532,9 @@ constexpr int C3D_RED = BM * C3D_FP * 4;                     // offset of the fp
 static_assert(C3D_RED + 2 * 128 * 8 <= C3D_MAIN, "staging of a column half + the fp64 sums fit the operand images");
 static_assert(3 * C3D_LDS <= 160 * 1024, "three workgroups per CU");
 
-template <typename T>
+// UP2: the head's 16 merged taps (four per class) over ONE 64-channel group; !UP2: a ConvTranspose stage's nine taps (1, 2, 2, 4 per class)
+// over C / 64 channel groups (cvd_kernel<T, 128, false> walks them in groups of 128: 256 registers, 76.5 KB)
+template <typename T, bool UP2>
 __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   typedef typename TT<T>::vec V;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
   constexpr int CSL = 8, PSTEP = NTHREADS / CSL;           // 8 slot columns of a halo pixel, 32 halo pixels between a thread's slots
   constexpr int NX = (C3D_NHP + PSTEP - 1) / PSTEP;        // 5
   const ConvArgs& a = g.c;
-  const Seg& sy = a.seg[0];  // dY (materialised gradient), 16 merged taps at stride 2
+  const Seg& sy = a.seg[0];  // dY (materialised gradient), taps at stride 2
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
   const T* ysrc = (const T*)sy.src + cx * SLOT;
   V rx[NX];
   // class (pa, pb): sub-grid pixel (y', x') = dY[2 y' + pa, 2 x' + pb]; its halo starts at (y0 - pa, x0 - pb)
-  auto issue_halo = [&](int pa, int pb, unsigned& ok) {
+  auto issue_halo = [&](int pa, int pb, int grp, unsigned& ok) {
     ok = 0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
       const int y = 2 * (y0 - pa + hy) + pa, x = 2 * (x0 - pb + hx) + pb;
       if (hp < C3D_NHP && (unsigned)y < (unsigned)sy.Hs && (unsigned)x < (unsigned)sy.Ws) ok |= 1u << i;
       const size_t pix = (size_t)(b * sy.Hs + min(max(y, 0), sy.Hs - 1)) * sy.Ws + min(max(x, 0), sy.Ws - 1);
-      rx[i] = *(const V*)(ysrc + pix * sy.ld);
+      rx[i] = *(const V*)(ysrc + pix * sy.ld + grp * 64);
     }
   };
   auto store_halo = [&](unsigned ok) {
@@ -598,8 +600,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
     const int piece = tid + NTHREADS * j, row = piece >> 2, slot = piece & 3;
     blds[j] = row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
   }
-  auto issue_b = [&](int tap) {
-    const int c0 = tap * cpt;
+  auto issue_b = [&](int tap, int grp) {
+    const int c0 = tap * cpt + grp * 2;
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
       const T* src = wp + ((size_t)(c0 + uu) * a.Npad + n0) * 32;
@@ -623,43 +625,59 @@ __global__ __launch_bounds__(NTHREADS, 3) void cvd3_kernel(const CvdArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // flat walk: class -> tap of the class (one stage of 2 chunks = the 64 channels).  Stage s of the walk uses B buffer s & 1.
+  // flat walk: class -> channel group of 64 -> tap of the class (one stage of 2 chunks).  Stage s of the walk uses B buffer s & 1.
+  const int ngrp = UP2 ? 1 : sy.C / 64;   // (the head: one group, known to the compiler - the walk is then straight-line code)
   int buf = 0;
+  int first_tap = 0;
   unsigned ok_cur = 0;
-  issue_halo(0, 0, ok_cur);
-  issue_b(g.tapidx[0]);
+  issue_halo(0, 0, 0, ok_cur);
+  issue_b(g.tapidx[0], 0);
 #pragma unroll
   for (int cls = 0; cls < 4; ++cls) {
     const int pa = cls >> 1, pb = cls & 1;
-    store_halo(ok_cur);
-    if (cls < 3) issue_halo((cls + 1) >> 1, (cls + 1) & 1, ok_cur);   // the next class's halo flies under this class's stages
+    const int ntap = UP2 ? 4 : (pa + 1) * (pb + 1);
+    for (int grp = 0; grp < ngrp; ++grp) {
+      store_halo(ok_cur);
+      // the next halo - next group of this class, or group 0 of the next class - flies under this group's stages
+      const bool last_grp = grp + 1 == ngrp;
+      if (!(last_grp && cls == 3)) {
+        const int ncls = last_grp ? cls + 1 : cls;
+        issue_halo(ncls >> 1, ncls & 1, last_grp ? 0 : grp + 1, ok_cur);
+      }
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int tap = g.tapidx[4 * cls + tt];
-      const int tw = sy.taps[tap];
-      const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
-      // halo pixel of the tap inside the class: row offset (dy + pa) / 2, likewise the column
-      const int hpt = hpl + ((dy + pa) >> 1) * CP_HW + ((dx + pb) >> 1);
-      const unsigned char* A = Xs + hpt * 128;
-      const int asw = (hpt >> 1) & 7;
-      store_b(buf);
-      __syncthreads();
-      if (4 * cls + tt + 1 < 16) issue_b(g.tapidx[4 * cls + tt + 1]);   // next stage's weights
-      const unsigned char* B = Bs + buf * CP_B_STAGE;
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt < ntap) {
+          const int tap = g.tapidx[first_tap + tt];
+          const int tw = sy.taps[tap];
+          const int dy = (int)(signed char)(tw & 0xff), dx = (int)(signed char)((tw >> 8) & 0xff);
+          // halo pixel of the tap inside the class: row offset (dy + pa) / 2, likewise the column
+          const int hpt = hpl + ((dy + pa) >> 1) * CP_HW + ((dx + pb) >> 1);
+          const unsigned char* A = Xs + hpt * 128;
+          const int asw = (hpt >> 1) & 7;
+          store_b(buf);
+          __syncthreads();
+          // next stage's weights
+          if (tt + 1 < ntap) issue_b(g.tapidx[first_tap + tt + 1], grp);
+          else if (!last_grp) issue_b(g.tapidx[first_tap], grp + 1);
+          else if (cls < 3) issue_b(g.tapidx[first_tap + ntap], 0);
+          const unsigned char* B = Bs + buf * CP_B_STAGE;
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu)
+          for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const V av = *(const V*)(A + (((uu * 4 + s * 2 + h) ^ asw) << 4));
+            for (int s = 0; s < 2; ++s) {
+              const V av = *(const V*)(A + (((uu * 4 + s * 2 + h) ^ asw) << 4));
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const V bv = *(const V*)(B + (uu * BN + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
-            acc[t] = mma16(av, bv, acc[t]);
-          }
+              for (int t = 0; t < NT; ++t) {
+                const V bv = *(const V*)(B + (uu * BN + 32 * t + r) * 64 + (((2 * s + h) ^ bsw) << 4));
+                acc[t] = mma16(av, bv, acc[t]);
+              }
+            }
+          buf ^= 1;
         }
-      buf ^= 1;
+      }
+      __syncthreads();  // every wave is done with this halo image
     }
-    __syncthreads();  // every wave is done with this halo image
+    first_tap += ntap;
   }
 
   // ---- epilogue in two column halves: fused BN+ReLU backward (see cvd_kernel / igemm.hip) ----
@@ -838,9 +856,9 @@ hipError_t launch_cvp(const ConvArgs& a, int dtype, int epi, hipStream_t st) {
   return x.ntaps == 4 ? launch_cvp_t<bf16, 4>(g, nwg, st) : (x.ntaps == 2 ? launch_cvp_t<bf16, 2>(g, nwg, st) : launch_cvp_t<bf16, 1>(g, nwg, st));
 }
 
-template <typename T>
+template <typename T, bool UP2>
 static hipError_t launch_cvd3_t(const CvdArgs& g, int nwg, hipStream_t st) {
-  auto kern = cvd3_kernel<T>;
+  auto kern = cvd3_kernel<T, UP2>;
   static bool attr_done = false;
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C3D_LDS);
@@ -892,7 +910,9 @@ static hipError_t launch_cvd(const ConvArgs& a, int dtype, hipStream_t st) {
   g.ntn = a.Npad / CP_BN;
   const int nwg = a.B * g.tiles_y * g.tiles_x * g.ntn;
   static const bool three = !lab_flag("DMM_NO_CVD3");
-  if (up2 && three) return dtype == DT_F16 ? launch_cvd3_t<f16>(g, nwg, st) : launch_cvd3_t<bf16>(g, nwg, st);
+  static const bool three_ct = !lab_flag("DMM_NO_CVD3_CT");
+  if (up2 && three) return dtype == DT_F16 ? launch_cvd3_t<f16, true>(g, nwg, st) : launch_cvd3_t<bf16, true>(g, nwg, st);
+  if (!up2 && three && three_ct) return dtype == DT_F16 ? launch_cvd3_t<f16, false>(g, nwg, st) : launch_cvd3_t<bf16, false>(g, nwg, st);
   if (up2) return dtype == DT_F16 ? launch_cvd_t<f16, 64, true>(g, nwg, st) : launch_cvd_t<bf16, 64, true>(g, nwg, st);
   return dtype == DT_F16 ? launch_cvd_t<f16, 128, false>(g, nwg, st) : launch_cvd_t<bf16, 128, false>(g, nwg, st);
 }
