@@ -170,6 +170,18 @@ def test_error_behaviour_matches_reference(lib):
         lib.check(lib.lib().dmm_plan_create(C.byref(d), C.byref(h)))
 
 
+def test_conv5_entry_point_refuses_other_shapes_without_a_gpu(lib):
+    """dmm_conv5_wgrad_stats (round 5) serves ONE shape family - the 5x5, pad 2, stride 1 convolution of 64 channels onto <= 4 behind
+    BN+ReLU in 16-bit storage - and says so before it touches the HIP runtime: DMM_ERR_INVALID with a message, never a launch with a
+    layout the kernel does not have (five classes would need a fifth column per tap)."""
+    L = lib.lib()
+    ok = dict(dtype=1, use_mfma=1, B=1, H=16, W=16, Cin=64, Cout=3, R=5, S=5, stride=1, pad=2, transposed=0, mode=0, bn_relu=1)
+    for change in (dict(Cout=5), dict(Cin=128), dict(R=3, S=3, pad=1), dict(dtype=0), dict(bn_relu=0), dict(stride=2), dict(use_mfma=0)):
+        d = lib.ConvDesc(**{**ok, **change})
+        rc = L.dmm_conv5_wgrad_stats(C.byref(d), None, None, None, None, None, None, None, None, None)
+        assert rc != 0 and b"5x5" in L.dmm_last_error(), (change, rc, L.dmm_last_error())
+
+
 def test_plan_flops_match_survey(lib):
     L = lib.lib()
     for (cbb, s2, want) in ((1, 3, 938.7), (3, 3, 1133.1)):
