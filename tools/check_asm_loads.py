@@ -75,6 +75,13 @@ def check_kernel(name, lines):
             events.append(("insn", regs_of(t.split(None, 1)[1]), no, t))
             events.append(("load", set(), no, t))
             continue
+        if t.startswith("global_load_lds_dwordx4") or (t.startswith("global_load_lds") and "dword" in t):
+            # an LDS-DMA request (the compiler's builtin or hand-written): it takes a slot of the in-order vmcnt queue like any load and
+            # writes no register (pig.hip's K-deep form interleaves the weight DMA with its hand-written row loads: the counted waits
+            # only mean what they say if the checker's queue holds both)
+            events.append(("insn", regs_of(t.split(None, 1)[1]), no, t))
+            events.append(("load", set(), no, t))
+            continue
         if in_asm and t.startswith("s_waitcnt") and "vmcnt" in t:
             n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
             events.append(("wait", n, no, t))
