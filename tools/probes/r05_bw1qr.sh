@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5: bw1 computing norm2's correction constants itself (the finalize launch off the chain) against the tables (DMM_NO_BW1_QR=1), same box
+# round 5 (record of an experiment; profiles/r05/ablations.txt): bw1 computing norm2's correction constants itself (the finalize launch off the
+# chain) against the tables, same box.  The switch DMM_NO_BW1_QR existed only in the experiment build (reverted: slower).
 out=gpurun_out/r05_bw1qr; mkdir -p $out
 for rep in 1 2; do
 for v in new old; do
